@@ -1,0 +1,240 @@
+/*
+ * colgrid.h -- C ABI of libcolgrid, the MI355X (gfx950) column-grid process engine.
+ *
+ * The library keeps one process-emulation grid per handle resident in HBM and runs
+ * every process step as hand-written HIP kernels.  The grid is a 2-D array of columns
+ * (index c = i*NY + j, j fastest); every column is a stack of (material, z0, z1) layers.
+ * On the device the stack is stored plane-major ("structure of arrays"):
+ *     len[c] u8,   mat[k*N + c] u8,   z0[k*N + c] u16,   z1[k*N + c] u16
+ * so that a wavefront touching layer k of 64 neighbouring columns reads contiguous bytes.
+ * cg_download / cg_upload convert to and from the reference's host layout
+ *     mat[c*Lmax + k],  zpair[2*(c*Lmax + k) + {0,1}],  len[c]
+ * (reference: template/script_columngrid.js:84-86, 111-112).
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes, returns an int status
+ * (0 = ok) and never throws.  A handle is not re-entrant: use it from one thread at a time.
+ * All work of a handle is enqueued on one HIP stream (its own, or the one given to
+ * cg_set_stream); entry points that return data to the host synchronise that stream.
+ *
+ * The comment above each declaration names the reference interface it stands in for.
+ * "cg1/cg2/rt/sl" = template/script_columngrid.js, script_columngrid2.js,
+ * script_runtime.js, script_slice2d.js of the reference.
+ */
+#ifndef COLGRID_H
+#define COLGRID_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------- */
+#define CG_OK               0
+#define CG_ERR_ARG          1   /* bad argument (null handle, unknown mask id, bad size ...)   */
+#define CG_ERR_HIP          2   /* a HIP runtime call failed; see cg_last_error               */
+#define CG_ERR_UNSUPPORTED  3   /* input outside what the engine reproduces bit-exactly        */
+#define CG_ERR_NOMEM        4
+#define CG_ERR_STATE        5   /* call sequence error (e.g. stencil_finish without begin)    */
+
+/* ---- material ids (cg1:7-8) --------------------------------------------------------- */
+#define CG_MAT_EMPTY   0
+#define CG_MAT_AIR     1
+#define CG_MAT_CAVITY  2
+#define CG_MAT_ALL     255
+
+#define CG_MASK_NONE  (-1)      /* "no mask": the step applies to every column               */
+
+typedef struct cg_grid cg_grid;   /* opaque */
+
+/* Domain and layout facts of a grid (fields of the reference's ColumnGrid object that the
+ * runtime and the consumers read: cg1:49-60, script_gridrenderer.js:216-218). */
+typedef struct cg_info {
+    int32_t nx, ny;            /* columns owned by this handle (a slab when nx < nx_global)  */
+    int32_t nx_global;         /* NX of the whole domain                                      */
+    int32_t i0;                /* global i index of local row 0                               */
+    int32_t lmax;              /* layers per column currently provisioned (reference: Lmax)   */
+    int32_t device;            /* HIP device ordinal                                          */
+    double  dx, dy, zscale;
+    double  offset_x, offset_y, lx_eff, ly_eff;   /* of the whole domain                      */
+} cg_info;
+
+/* One mask shape, already reduced to numbers (rt:73-129).  The host computes cos/sin of
+ * rad = (-angle*PI)/180 itself so that only ONE libm (the caller's) is ever involved.
+ * Invisible objects (rt:62) are dropped by the host and never reach the library. */
+#define CG_SHAPE_RECT     0
+#define CG_SHAPE_CIRCLE   1
+#define CG_SHAPE_ELLIPSE  2
+#define CG_SHAPE_POLYGON  3   /* also 'path': its M/L vertices (rt:119-124)                  */
+#define CG_SHAPE_NEVER    4   /* any other fabric type: never contains a point (rt:126)      */
+typedef struct cg_shape {
+    int32_t type;
+    int32_t positive;          /* polarity 'positive' (default): a hit BLOCKS the step (rt:65) */
+    int32_t rotated;           /* angle !== 0 (rt:87)                                          */
+    int32_t pt_off, pt_cnt;    /* polygon: range in the points array (pairs x,y)               */
+    int32_t _pad;
+    double  left, top, w, h;   /* obj.left||0, obj.top||0, obj.width||0, obj.height||0         */
+    double  cosr, sinr;        /* Math.cos(rad), Math.sin(rad)                                 */
+    double  scale_x, scale_y;  /* obj.scaleX||1, obj.scaleY||1                                 */
+    double  a, b;              /* circle: a = radius||w/2.  ellipse: a = rx||w/2, b = ry||h/2  */
+} cg_shape;
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* new ColumnGrid(LXnm, LYnm, dx, dy, LmaxInit=32, zScale=0.1) (cg1:21-38, 49-60):
+ * NX = max(1, round(LX/dx)), NY likewise; Lmax = nextPowerOf2(LmaxInit) (cg1:302-304);
+ * all columns empty.  The grid lives on the current HIP device. */
+int cg_create(double lx_nm, double ly_nm, double dx, double dy,
+              int lmax_init, double zscale, cg_grid** out);
+
+/* A slab of a larger domain: rows i in [i0, i0+nx_local) of an nx_global x ny grid.
+ * No counterpart in the reference (it is single-threaded); used for the 1-D domain
+ * decomposition over GPUs.  Mask rasters use global cell centres (cg1:448). */
+int cg_create_slab(int nx_global, int ny, int i0, int nx_local, double dx, double dy,
+                   int lmax_init, double zscale, cg_grid** out);
+
+int cg_destroy(cg_grid* g);
+
+/* createNewGrid(LmaxInit = this.Lmax) (cg1:40-43): re-provision at nextPowerOf2(lmax_init)
+ * layers (pass 0 to keep the current Lmax) and empty every column. */
+int cg_reset(cg_grid* g, int lmax_init);
+
+/* clearAll() (cg1:223-227): empty every column, keep Lmax. */
+int cg_clear(cg_grid* g);
+
+int cg_get_info(const cg_grid* g, cg_info* out);
+
+/* Text of the last error on this handle (or, for g == NULL, of the last failed create on
+ * the calling thread).  Valid until the next call on the handle. */
+const char* cg_last_error(const cg_grid* g);
+
+/* Use the caller's HIP stream (hipStream_t passed as void*) for all work of this handle;
+ * NULL switches back to the handle's own stream. */
+int cg_set_stream(cg_grid* g, void* hip_stream);
+int cg_sync(cg_grid* g);
+
+/* ---- masks (rt:45-141) --------------------------------------------------------------- */
+
+/* A mask is a per-column predicate "the step applies here", stored on the device as one
+ * byte per column (1 = open), order c = i*NY + j, evaluated at the cell centre
+ * x = (i+0.5)*dx, y = (j+0.5)*dy (cg1:448).  Ids are small non-negative integers. */
+
+/* From a host raster the caller filled by evaluating maskFn at every centre of THIS
+ * handle's columns (nx*ny bytes, non-zero = open). */
+int cg_mask_from_raster(cg_grid* g, const uint8_t* host_raster, size_t n, int* mask_id);
+
+/* Same, from a raster already in device memory (copied). */
+int cg_mask_from_device_raster(cg_grid* g, const void* dev_raster, size_t n, int* mask_id);
+
+/* From the shape list of a mask record: _isPointBlocked(x, y, maskData) (rt:54-71) run on
+ * the device.  shapes[] are the VISIBLE objects in their original order; the walk is from
+ * the last to the first and the first containing shape decides.  pts = polygon vertices
+ * (x0,y0,x1,y1,...), npts = number of doubles / 2. */
+int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes,
+                        const double* pts, int npts, int* mask_id);
+
+int cg_mask_download(cg_grid* g, int mask_id, uint8_t* host_out, size_t n);
+int cg_mask_destroy(cg_grid* g, int mask_id);
+
+/* ---- process steps ------------------------------------------------------------------- */
+
+/* deposit_general(maskFn, matId, thickness, conformality) (cg1:435-544).
+ * t<=0: no-op.  S clamped to [0,1].  t*S < min(dx,dy): vertical deposit on open columns
+ * (cg1:445-454).  Otherwise conformal growth by an ellipsoidal max-plus dilation of the
+ * top-height map (cg1:457-540) followed by identify_cavity (cg1:543). */
+int cg_deposit_general(cg_grid* g, int mask_id, int mat, double thickness, double conformality);
+
+/* etch_general(maskFn, matId, thickness, conformality) (cg1:598-740); mat 255 = ALL. */
+int cg_etch_general(cg_grid* g, int mask_id, int mat, double thickness, double conformality);
+
+/* cmp(depth, stopMatId) (cg1:747-859). */
+int cg_cmp(cg_grid* g, double depth, int stop_mat);
+
+/* strip_connected(matId) (cg1:867 - cg2:1). */
+int cg_strip_connected(cg_grid* g, int mat);
+
+/* identify_cavity() (cg2:9-83). */
+int cg_identify_cavity(cg_grid* g);
+
+/* maxHeight() (cg2:85-104): max top z over this handle's columns in nm, 1 if that is 0.
+ * top_q receives the quantised maximum (0 for an empty grid); either pointer may be NULL. */
+int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q);
+
+/* ---- lateral-stencil steps split in two for the multi-GPU halo exchange --------------
+ * No counterpart in the reference.  cg_deposit_general / cg_etch_general on a slab whose
+ * neighbours matter are run as:
+ *   cg_stencil_begin  -> snapshot of the top heights (+ etchable flags) of the slab,
+ *                        returns the stencil radius R in rows (0: vertical fast path or
+ *                        no-op, nothing to exchange, the step is already complete);
+ *   cg_halo_buffers   -> device pointers of the rows to send to / receive from the lower
+ *                        (i-1) and upper (i+1) neighbour, each R*ny*3 bytes
+ *                        (u16 top height rows followed by u8 etchable-flag rows);
+ *   (caller moves the bytes, e.g. with RCCL send/recv on the handle's stream)
+ *   cg_stencil_finish -> dilation / erosion and the per-column update.
+ * has_lower / has_upper = 0 means domain edge: heights are clamp-replicated and flags are
+ * zero there (cg1:373-387, 671).
+ */
+#define CG_STENCIL_DEPOSIT 0
+#define CG_STENCIL_ETCH    1
+int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thickness,
+                     double conformality, int has_lower, int has_upper, int* radius_rows);
+int cg_halo_buffers(cg_grid* g, void** send_lower, void** send_upper,
+                    void** recv_lower, void** recv_upper, size_t* bytes_each);
+int cg_stencil_finish(cg_grid* g);
+
+/* ---- data exchange with the host (the `cols` contract, script_gridrenderer.js:216-263) */
+
+/* Copy the grid into caller-owned arrays in the reference layout with stride lmax
+ * (cg_info.lmax): mat[n*lmax], zpair[2*n*lmax], len[n], n = nx*ny.  Dead slots are 0. */
+int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len);
+
+/* Replace the grid by host arrays in the reference layout with the given stride
+ * (loadCache's restore, cg1:276-278).  lmax becomes the handle's Lmax. */
+int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8_t* len, int lmax);
+
+/* Device-side snapshots: saveCache / loadCache keep the grid in HBM (cg1:247-282); the
+ * use-count / eviction policy stays with the host.  Slots are caller-chosen ints >= 0. */
+int cg_snapshot_save(cg_grid* g, int slot);
+int cg_snapshot_load(cg_grid* g, int slot);
+int cg_snapshot_drop(cg_grid* g, int slot);
+
+/* Cross-sections (sl:18-40): copy `count` whole grid lines into host arrays in the reference
+ * layout.  axis 0 = 'YZ' (fixed i = index[s], ny columns each), axis 1 = 'XZ' (fixed j,
+ * nx columns each).  Output s starts at s*line_cols*lmax (mat), 2*that (zpair),
+ * s*line_cols (len). */
+int cg_slices(cg_grid* g, int axis, const int32_t* index, int count,
+              uint8_t* mat, uint16_t* zpair, uint8_t* len);
+/* Same but leaves the result in device memory owned by the handle (valid until the next
+ * cg_slices* call); for consumers that stay on the GPU. */
+int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count,
+                     void** d_mat, void** d_zpair, void** d_len);
+
+/* indexFromX / indexFromY (sl:15-16): clamp(round((pos - offset)/pitch), 0, n-1). */
+int cg_index_from_pos(const cg_grid* g, int axis, double pos_nm, int32_t* index);
+
+/* ---- checks and measurement ---------------------------------------------------------- */
+
+/* Order-independent 64-bit checksum of the live layers: sum over columns of a per-column
+ * hash of (global column index, len, mat/z0q/z1q of each live layer), mod 2^64.  The sum
+ * over the slabs of a decomposed grid equals the checksum of the whole grid. */
+int cg_checksum(cg_grid* g, uint64_t* sum);
+
+/* Column counts per case of the last step, for the algorithmic-byte model:
+ * [0] columns visited, [1] open (mask) columns, [2] top layer extended, [3] new layer
+ * appended, [4] columns etched, [5] whole layers removed, [6] layers scanned for the floor. */
+#define CG_NSTAT 8
+int cg_step_stats(cg_grid* g, int enable, uint64_t stats[CG_NSTAT]);
+
+/* HIP-event timing on the handle's stream: cg_timer_start records an event, cg_timer_stop
+ * records a second one, waits for it and returns the elapsed milliseconds in between. */
+int cg_timer_start(cg_grid* g);
+int cg_timer_stop(cg_grid* g, float* ms);
+
+/* Library version string, e.g. "colgrid 0.1 gfx950". */
+const char* cg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLGRID_H */
