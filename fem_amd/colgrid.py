@@ -1,0 +1,411 @@
+"""ctypes view of libcolgrid's C ABI (include/colgrid.h) with the reference's method names.
+
+`ColumnGrid` mirrors the call surface of the reference's ColumnGrid class
+(template/script_columngrid.js:12-43, 435, 598, 747, 867; script_columngrid2.js:9, 85):
+same method names, argument order and "bad input is a silent no-op" behaviour.  The one
+difference is the mask argument: the reference takes a JavaScript closure maskFn(x, y); here a
+mask is a device raster built once per mask (`Mask`), `None` meaning "no mask".
+
+There is no CPU fallback: if the HIP library cannot be loaded every constructor raises.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcolgrid.so")
+
+CG_MASK_NONE = -1
+CG_NSTAT = 8
+STENCIL_DEPOSIT, STENCIL_ETCH = 0, 1
+SHAPE_RECT, SHAPE_CIRCLE, SHAPE_ELLIPSE, SHAPE_POLYGON, SHAPE_NEVER = range(5)
+
+
+class ColGridError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcolgrid error {code}: {msg}")
+        self.code = code
+
+
+class CgInfo(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nx_global", C.c_int32), ("i0", C.c_int32),
+                ("lmax", C.c_int32), ("device", C.c_int32),
+                ("dx", C.c_double), ("dy", C.c_double), ("zscale", C.c_double),
+                ("offset_x", C.c_double), ("offset_y", C.c_double), ("lx_eff", C.c_double), ("ly_eff", C.c_double)]
+
+
+class CgShape(C.Structure):
+    _fields_ = [("type", C.c_int32), ("positive", C.c_int32), ("rotated", C.c_int32),
+                ("pt_off", C.c_int32), ("pt_cnt", C.c_int32), ("_pad", C.c_int32),
+                ("left", C.c_double), ("top", C.c_double), ("w", C.c_double), ("h", C.c_double),
+                ("cosr", C.c_double), ("sinr", C.c_double), ("scale_x", C.c_double), ("scale_y", C.c_double),
+                ("a", C.c_double), ("b", C.c_double)]
+
+
+# every symbol include/colgrid.h declares, with its ctypes signature
+_vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+ABI = {
+    "cg_create": (_i, [_d, _d, _d, _d, _i, _d, _pp]),
+    "cg_create_slab": (_i, [_i, _i, _i, _i, _d, _d, _i, _d, _pp]),
+    "cg_destroy": (_i, [_vp]),
+    "cg_reset": (_i, [_vp, _i]),
+    "cg_clear": (_i, [_vp]),
+    "cg_get_info": (_i, [_vp, C.POINTER(CgInfo)]),
+    "cg_last_error": (C.c_char_p, [_vp]),
+    "cg_set_stream": (_i, [_vp, _vp]),
+    "cg_sync": (_i, [_vp]),
+    "cg_mask_from_raster": (_i, [_vp, _vp, _sz, C.POINTER(_i)]),
+    "cg_mask_from_device_raster": (_i, [_vp, _vp, _sz, C.POINTER(_i)]),
+    "cg_mask_from_shapes": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(_i)]),
+    "cg_mask_download": (_i, [_vp, _i, _vp, _sz]),
+    "cg_mask_destroy": (_i, [_vp, _i]),
+    "cg_deposit_general": (_i, [_vp, _i, _i, _d, _d]),
+    "cg_etch_general": (_i, [_vp, _i, _i, _d, _d]),
+    "cg_cmp": (_i, [_vp, _d, _i]),
+    "cg_strip_connected": (_i, [_vp, _i]),
+    "cg_identify_cavity": (_i, [_vp]),
+    "cg_max_height": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_uint32)]),
+    "cg_stencil_begin": (_i, [_vp, _i, _i, _i, _d, _d, _i, _i, C.POINTER(_i)]),
+    "cg_halo_buffers": (_i, [_vp, _pp, _pp, _pp, _pp, C.POINTER(_sz)]),
+    "cg_stencil_finish": (_i, [_vp]),
+    "cg_download": (_i, [_vp, _vp, _vp, _vp]),
+    "cg_upload": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "cg_snapshot_save": (_i, [_vp, _i]),
+    "cg_snapshot_load": (_i, [_vp, _i]),
+    "cg_snapshot_drop": (_i, [_vp, _i]),
+    "cg_slices": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "cg_slices_device": (_i, [_vp, _i, _vp, _i, _pp, _pp, _pp]),
+    "cg_index_from_pos": (_i, [_vp, _i, _d, C.POINTER(C.c_int32)]),
+    "cg_checksum": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "cg_step_stats": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
+    "cg_timer_start": (_i, [_vp]),
+    "cg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "cg_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libcolgrid.so and bind every ABI symbol.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ColGridError(-1, f"{p} not found: build it with `make -C fem_amd/csrc` (hipcc, gfx950)")
+    lib = C.CDLL(p)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def reduce_mask(mask_data):
+    """Python twin of fem_amd/js/maskshapes.js: fabric JSON -> {'open', 'shapes', 'pts'}.
+
+    Follows template/script_runtime.js:54-129 of the reference.  cos/sin come from this
+    process's libm; a JavaScript host passes its own values instead.
+    """
+    if not mask_data or not mask_data.get("objects"):
+        if not mask_data or "objects" not in mask_data or mask_data["objects"] is None:
+            return {"open": True, "shapes": [], "pts": []}
+    shapes, pts = [], []
+    for obj in mask_data["objects"]:
+        if not obj.get("visible"):
+            continue
+        left, top = obj.get("left") or 0, obj.get("top") or 0
+        w, h = obj.get("width") or 0, obj.get("height") or 0
+        angle = obj.get("angle") or 0
+        sx, sy = obj.get("scaleX") or 1, obj.get("scaleY") or 1
+        polarity = (obj.get("data") or {}).get("polarity") or "positive"
+        positive = 1 if polarity == "positive" else 0
+        rotated = 1 if angle != 0 else 0
+        cosr, sinr = 1.0, 0.0
+        if rotated:
+            rad = (-angle * math.pi) / 180
+            cosr, sinr = math.cos(rad), math.sin(rad)
+        typ, a, b, off, cnt = SHAPE_NEVER, 0.0, 0.0, 0, 0
+        t = obj.get("type")
+        if t == "rect":
+            typ = SHAPE_RECT
+        elif t == "circle":
+            typ, a = SHAPE_CIRCLE, (obj.get("radius") or w / 2)
+        elif t == "ellipse":
+            typ, a, b = SHAPE_ELLIPSE, (obj.get("rx") or w / 2), (obj.get("ry") or h / 2)
+        elif t == "polygon":
+            if obj.get("points") is None:
+                raise TypeError("polygon without points")
+            typ, off, cnt = SHAPE_POLYGON, len(pts) // 2, len(obj["points"])
+            for p in obj["points"]:
+                pts += [p["x"], p["y"]]
+        elif t == "path" and obj.get("path"):
+            typ, off = SHAPE_POLYGON, len(pts) // 2
+            for p in obj["path"]:
+                if p[0] in ("L", "M"):
+                    pts += [p[1], p[2]]; cnt += 1
+        shapes.append([typ, positive, rotated, off, cnt, left, top, w, h, cosr, sinr, sx, sy, a, b])
+    return {"open": False, "shapes": shapes, "pts": pts}
+
+
+def _pack_shapes(reduced):
+    n = len(reduced["shapes"])
+    arr = (CgShape * max(1, n))()
+    for s, r in enumerate(reduced["shapes"]):
+        arr[s].type, arr[s].positive, arr[s].rotated, arr[s].pt_off, arr[s].pt_cnt = [int(v) for v in r[:5]]
+        (arr[s].left, arr[s].top, arr[s].w, arr[s].h, arr[s].cosr, arr[s].sinr,
+         arr[s].scale_x, arr[s].scale_y, arr[s].a, arr[s].b) = [float(v) for v in r[5:15]]
+    pts = np.ascontiguousarray(reduced["pts"], dtype=np.float64)
+    return arr, n, pts
+
+
+class Mask:
+    """A device raster of one mask for one grid."""
+
+    def __init__(self, grid, mask_id):
+        self.grid, self.id = grid, mask_id
+
+    def download(self):
+        out = np.empty(self.grid.NX * self.grid.NY, np.uint8)
+        self.grid._chk(self.grid.lib.cg_mask_download(self.grid.h, self.id, out.ctypes.data, out.size))
+        return out
+
+    def destroy(self):
+        if self.id is not None and self.grid.h:
+            self.grid.lib.cg_mask_destroy(self.grid.h, self.id)
+        self.id = None
+
+
+class ColumnGrid:
+    """The reference's ColumnGrid call surface over libcolgrid.
+
+    ColumnGrid(LXnm, LYnm, dx, dy, LmaxInit=32, zScale=0.1) as script_columngrid.js:21.
+    slab=(nx_global, ny, i0, nx_local) makes a slab of a larger domain instead (multi-GPU).
+    """
+
+    def __init__(self, LXnm=None, LYnm=None, dx=2.0, dy=2.0, LmaxInit=32, zScale=0.1, *, slab=None, lib=None):
+        self.lib = lib or load_library()
+        self.h = None
+        out = C.c_void_p()
+        if slab is not None:
+            nxg, ny, i0, nxl = slab
+            rc = self.lib.cg_create_slab(nxg, ny, i0, nxl, dx, dy, LmaxInit, zScale, C.byref(out))
+        else:
+            rc = self.lib.cg_create(LXnm, LYnm, dx, dy, LmaxInit, zScale, C.byref(out))
+        if rc:
+            raise ColGridError(rc, (self.lib.cg_last_error(None) or b"").decode())
+        self.h = out
+        self.nMaxCache = 10
+        self._info = None
+
+    # ---- plumbing
+    def _chk(self, rc):
+        if rc:
+            raise ColGridError(rc, (self.lib.cg_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.lib.cg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        inf = CgInfo()
+        self._chk(self.lib.cg_get_info(self.h, C.byref(inf)))
+        return inf
+
+    NX = property(lambda s: s.info().nx)
+    NY = property(lambda s: s.info().ny)
+    Lmax = property(lambda s: s.info().lmax)
+    dx = property(lambda s: s.info().dx)
+    dy = property(lambda s: s.info().dy)
+    offsetX = property(lambda s: s.info().offset_x)
+    offsetY = property(lambda s: s.info().offset_y)
+    LXeff = property(lambda s: s.info().lx_eff)
+    LYeff = property(lambda s: s.info().ly_eff)
+
+    def sync(self):
+        self._chk(self.lib.cg_sync(self.h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.lib.cg_set_stream(self.h, stream_ptr))
+
+    # ---- masks
+    def mask_from_raster(self, raster):
+        r = np.ascontiguousarray(raster, dtype=np.uint8).reshape(-1)
+        mid = C.c_int()
+        self._chk(self.lib.cg_mask_from_raster(self.h, r.ctypes.data, r.size, C.byref(mid)))
+        return Mask(self, mid.value)
+
+    def mask_from_device_raster(self, dev_ptr, n):
+        mid = C.c_int()
+        self._chk(self.lib.cg_mask_from_device_raster(self.h, dev_ptr, n, C.byref(mid)))
+        return Mask(self, mid.value)
+
+    def mask_from_shapes(self, reduced):
+        """reduced: output of reduce_mask() / maskshapes.js reduceMask()."""
+        arr, n, pts = _pack_shapes(reduced)
+        mid = C.c_int()
+        self._chk(self.lib.cg_mask_from_shapes(self.h, C.cast(arr, C.c_void_p), n,
+                                               pts.ctypes.data if pts.size else None, pts.size // 2, C.byref(mid)))
+        return Mask(self, mid.value)
+
+    def mask_from_data(self, mask_data):
+        red = reduce_mask(mask_data)
+        return None if red["open"] else self.mask_from_shapes(red)
+
+    @staticmethod
+    def _mid(mask):
+        if mask is None:
+            return CG_MASK_NONE
+        if isinstance(mask, Mask):
+            return mask.id
+        raise TypeError("mask must be None or a Mask made by this grid (mask_from_raster / mask_from_shapes)")
+
+    # ---- the reference's step methods
+    def deposit_general(self, mask, matId, thickness, conformality=1.0):
+        self._chk(self.lib.cg_deposit_general(self.h, self._mid(mask), int(matId), float(thickness), float(conformality)))
+
+    def etch_general(self, mask, matId, thickness, conformality=1.0):
+        self._chk(self.lib.cg_etch_general(self.h, self._mid(mask), int(matId), float(thickness), float(conformality)))
+
+    def cmp(self, depth, stopMatId=0):
+        self._chk(self.lib.cg_cmp(self.h, float(depth), int(stopMatId)))
+
+    def strip_connected(self, matId):
+        self._chk(self.lib.cg_strip_connected(self.h, int(matId)))
+
+    def identify_cavity(self):
+        self._chk(self.lib.cg_identify_cavity(self.h))
+
+    def maxHeight(self):
+        z = C.c_double()
+        self._chk(self.lib.cg_max_height(self.h, C.byref(z), None))
+        return z.value
+
+    max_height = maxHeight
+
+    def createNewGrid(self, LmaxInit=0):
+        self._chk(self.lib.cg_reset(self.h, int(LmaxInit)))
+
+    reset = createNewGrid
+
+    def clearAll(self):
+        self._chk(self.lib.cg_clear(self.h))
+
+    # ---- split stencil steps (multi-GPU)
+    def stencil_begin(self, kind, mask, matId, thickness, conformality, has_lower, has_upper):
+        R = C.c_int()
+        self._chk(self.lib.cg_stencil_begin(self.h, kind, self._mid(mask), int(matId), float(thickness),
+                                            float(conformality), int(has_lower), int(has_upper), C.byref(R)))
+        return R.value
+
+    def halo_buffers(self):
+        p = [C.c_void_p() for _ in range(4)]
+        n = C.c_size_t()
+        self._chk(self.lib.cg_halo_buffers(self.h, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]), C.byref(p[3]), C.byref(n)))
+        return [q.value for q in p], n.value
+
+    def stencil_finish(self):
+        self._chk(self.lib.cg_stencil_finish(self.h))
+
+    # ---- data exchange
+    def download(self):
+        """(len, mat, zpair) in the reference layout with stride Lmax."""
+        inf = self.info()
+        n, L = inf.nx * inf.ny, inf.lmax
+        ln = np.empty(n, np.uint8); mat = np.empty(n * L, np.uint8); zp = np.empty(2 * n * L, np.uint16)
+        self._chk(self.lib.cg_download(self.h, mat.ctypes.data, zp.ctypes.data, ln.ctypes.data))
+        return ln, mat, zp
+
+    arrays = download
+
+    @property
+    def cols(self):
+        ln, mat, zp = self.download()
+        return {"mat": mat, "zpair": zp, "len": ln}
+
+    def upload(self, ln, mat, zp, lmax):
+        ln = np.ascontiguousarray(ln, np.uint8); mat = np.ascontiguousarray(mat, np.uint8)
+        zp = np.ascontiguousarray(zp, np.uint16)
+        n = self.NX * self.NY
+        if ln.size != n or mat.size != n * lmax or zp.size != 2 * n * lmax:
+            raise ValueError("array sizes do not match the grid")
+        self._chk(self.lib.cg_upload(self.h, mat.ctypes.data, zp.ctypes.data, ln.ctypes.data, int(lmax)))
+
+    def snapshot_save(self, slot):
+        self._chk(self.lib.cg_snapshot_save(self.h, int(slot)))
+
+    def snapshot_load(self, slot):
+        self._chk(self.lib.cg_snapshot_load(self.h, int(slot)))
+
+    def snapshot_drop(self, slot):
+        self._chk(self.lib.cg_snapshot_drop(self.h, int(slot)))
+
+    def slices(self, axis, indices):
+        """axis 'YZ' (fixed i) or 'XZ' (fixed j): list of (len, mat, zpair) per requested line."""
+        ax = {"YZ": 0, "XZ": 1}[axis] if isinstance(axis, str) else int(axis)
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        inf = self.info()
+        line = inf.ny if ax == 0 else inf.nx
+        L, cnt = inf.lmax, idx.size
+        ln = np.empty(cnt * line, np.uint8); mat = np.empty(cnt * line * L, np.uint8)
+        zp = np.empty(2 * cnt * line * L, np.uint16)
+        self._chk(self.lib.cg_slices(self.h, ax, idx.ctypes.data, cnt, mat.ctypes.data, zp.ctypes.data, ln.ctypes.data))
+        return ln.reshape(cnt, line), mat.reshape(cnt, line, L), zp.reshape(cnt, line, L, 2)
+
+    def slices_device(self, axis, indices):
+        ax = {"YZ": 0, "XZ": 1}[axis] if isinstance(axis, str) else int(axis)
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        self._chk(self.lib.cg_slices_device(self.h, ax, idx.ctypes.data, idx.size, None, None, None))
+
+    def index_from_pos(self, axis, pos):
+        out = C.c_int32()
+        self._chk(self.lib.cg_index_from_pos(self.h, int(axis), float(pos), C.byref(out)))
+        return out.value
+
+    # ---- checks and measurement
+    def checksum(self):
+        s = C.c_uint64()
+        self._chk(self.lib.cg_checksum(self.h, C.byref(s)))
+        return s.value
+
+    def fnv(self):
+        """FNV-1a/32 of the live layers (host side, after a download); small grids only."""
+        ln, mat, zp = self.download()
+        L = self.Lmax
+        h = 2166136261
+        for c in range(ln.size):
+            l = int(ln[c]); h = ((h ^ l) * 16777619) & 0xFFFFFFFF
+            for k in range(l):
+                b = c * L + k
+                for v in (int(mat[b]), int(zp[2 * b]), int(zp[2 * b + 1])):
+                    h = ((h ^ v) * 16777619) & 0xFFFFFFFF
+        return "%08x" % h
+
+    def stats_enable(self, on=True):
+        self._chk(self.lib.cg_step_stats(self.h, 1 if on else 0, None))
+
+    def stats(self):
+        out = (C.c_uint64 * CG_NSTAT)()
+        self._chk(self.lib.cg_step_stats(self.h, 1, out))
+        return list(out)
+
+    def timer_start(self):
+        self._chk(self.lib.cg_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.lib.cg_timer_stop(self.h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,820 @@
+// libcolgrid: host side of the C ABI declared in include/colgrid.h.
+// Owns the device planes of a grid, the mask rasters, the conformal-kernel cache and the
+// stencil scratch; enqueues the kernels of cg_kernels.hip.h on the handle's stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/colgrid.h"
+#include "cg_kernels.hip.h"
+
+using namespace cgk;
+
+namespace {
+
+thread_local std::string t_create_error;
+
+// One cached conformal kernel (script_columngrid.js:324-357): radius, the thickness it was
+// built for (the reference reuses it as `baseAdd` on a cache hit) and its taps on the device.
+struct ConfKernel {
+    int key[4];
+    int Rx;
+    double baseAdd;
+    std::vector<int> du, dv;
+    std::vector<float> add;
+    Tap* d_taps = nullptr;  int ntaps = 0;       // float32-exact taps
+    Tap* d_taps64 = nullptr; int ntaps64 = 0;    // taps that must be evaluated in double
+    int dev_R = -1;                              // pitch the device offsets were built for
+};
+
+struct Snapshot {
+    uint8_t* len = nullptr; uint8_t* mat = nullptr; uint16_t* z0 = nullptr; uint16_t* z1 = nullptr;
+    int lmax = 0; int len_bound = 0; bool has_gaps = false;
+};
+
+struct Pending {
+    bool active = false;
+    int kind = 0, mask_id = CG_MASK_NONE, mat = 0, R = 0;
+    double t_eff = 0;
+    ConfKernel* K = nullptr;
+    bool has_lower = false, has_upper = false;
+};
+
+}  // namespace
+
+struct cg_grid {
+    int device = 0;
+    int nx = 0, ny = 0, nx_global = 0, i0 = 0;
+    size_t N = 0;
+    double dx = 0, dy = 0, zscale = 0.1;
+    int lmax = 32;
+    uint8_t* len = nullptr; uint8_t* mat = nullptr; uint16_t* z0 = nullptr; uint16_t* z1 = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::vector<uint8_t*> masks;
+    std::deque<ConfKernel*> kcache;
+    // stencil scratch
+    uint16_t* topq = nullptr; uint8_t* eflag = nullptr; size_t img_cap = 0;     // capacity in elements
+    uint8_t* halo[4] = {nullptr, nullptr, nullptr, nullptr}; size_t halo_cap = 0;  // send lo/up, recv lo/up
+    Pending pend;
+    std::map<int, Snapshot> snaps;
+    // invariants tracked on the host
+    int len_bound = 0;          // upper bound of max(len); INT32_MAX = unknown
+    bool has_gaps = false;      // some column may have a vertical gap between layers
+    // small device words: flags[0] overflow, [1] any etchable, [2] gap seen; red[0..1] reductions
+    int* d_flags = nullptr; unsigned* d_red = nullptr; unsigned long long* d_sum = nullptr;
+    unsigned long long* d_stats = nullptr; bool stats_on = false; uint64_t stats_host[CG_NSTAT] = {0};
+    // slice staging
+    uint8_t* sl_mat = nullptr; uint16_t* sl_zp = nullptr; uint8_t* sl_len = nullptr; size_t sl_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+};
+
+namespace {
+
+int fail(cg_grid* g, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (g) g->err = buf; else t_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(g, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail(g, e__ == hipErrorOutOfMemory ? CG_ERR_NOMEM : CG_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                        hipGetErrorString(e__), __FILE__, __LINE__);                          \
+    } while (0)
+
+#define NEED(g)                                                                               \
+    do { if (!(g)) return fail(nullptr, CG_ERR_ARG, "null handle");                           \
+         hipError_t e__ = hipSetDevice((g)->device);                                          \
+         if (e__ != hipSuccess) return fail(g, CG_ERR_HIP, "hipSetDevice(%d): %s", (g)->device, hipGetErrorString(e__)); } while (0)
+
+double js_round(double x) { double r = std::floor(x); if (x - r >= 0.5) r += 1.0; return r; }
+
+int next_pow2(int n) {                       // script_columngrid.js:302-304
+    int v = std::max(1, n - 1);
+    return 1 << (32 - __builtin_clz((unsigned)v));
+}
+
+int js_to_int32(double v) {                  // (v | 0)
+    if (!std::isfinite(v)) return 0;
+    double m = std::fmod(std::trunc(v), 4294967296.0);
+    if (m < 0) m += 4294967296.0;
+    return (int)(uint32_t)m;
+}
+
+GridView view(const cg_grid* g) {
+    GridView v;
+    v.len = g->len; v.mat = g->mat; v.z0 = g->z0; v.z1 = g->z1;
+    v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.zs = g->zscale;
+    return v;
+}
+
+unsigned blocks_for(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (unsigned)std::min<size_t>(std::max<size_t>(b, 1), 256 * 16);
+}
+
+void free_planes(cg_grid* g) {
+    if (g->len) (void)hipFree(g->len);
+    if (g->mat) (void)hipFree(g->mat);
+    if (g->z0) (void)hipFree(g->z0);
+    if (g->z1) (void)hipFree(g->z1);
+    g->len = g->mat = nullptr; g->z0 = g->z1 = nullptr;
+}
+
+int alloc_planes(cg_grid* g, int lmax) {
+    free_planes(g);
+    size_t S = g->N * (size_t)lmax;
+    HIPCHK(g, hipMalloc(&g->len, std::max<size_t>(g->N, 1)));
+    HIPCHK(g, hipMalloc(&g->mat, std::max<size_t>(S, 1)));
+    HIPCHK(g, hipMalloc(&g->z0, std::max<size_t>(2 * S, 2)));
+    HIPCHK(g, hipMalloc(&g->z1, std::max<size_t>(2 * S, 2)));
+    g->lmax = lmax;
+    return CG_OK;
+}
+
+int zero_planes(cg_grid* g) {
+    size_t S = g->N * (size_t)g->lmax;
+    HIPCHK(g, hipMemsetAsync(g->len, 0, g->N, g->stream));
+    HIPCHK(g, hipMemsetAsync(g->mat, 0, S, g->stream));
+    HIPCHK(g, hipMemsetAsync(g->z0, 0, 2 * S, g->stream));
+    HIPCHK(g, hipMemsetAsync(g->z1, 0, 2 * S, g->stream));
+    g->len_bound = 0; g->has_gaps = false;
+    return CG_OK;
+}
+
+// _expandBuffers (script_columngrid.js:129-168): Lmax += 16.  Plane-major storage makes the old
+// contents a prefix of the new allocation: one copy per array, no re-striding.
+int grow_planes(cg_grid* g) {
+    const int newL = g->lmax + 16;
+    size_t So = g->N * (size_t)g->lmax, Sn = g->N * (size_t)newL;
+    uint8_t* nm = nullptr; uint16_t *n0 = nullptr, *n1 = nullptr;
+    HIPCHK(g, hipMalloc(&nm, Sn)); HIPCHK(g, hipMalloc(&n0, 2 * Sn)); HIPCHK(g, hipMalloc(&n1, 2 * Sn));
+    HIPCHK(g, hipMemcpyAsync(nm, g->mat, So, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(n0, g->z0, 2 * So, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(n1, g->z1, 2 * So, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemsetAsync(nm + So, 0, Sn - So, g->stream));
+    HIPCHK(g, hipMemsetAsync(n0 + So, 0, 2 * (Sn - So), g->stream));
+    HIPCHK(g, hipMemsetAsync(n1 + So, 0, 2 * (Sn - So), g->stream));
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    (void)hipFree(g->mat); (void)hipFree(g->z0); (void)hipFree(g->z1);
+    g->mat = nm; g->z0 = n0; g->z1 = n1; g->lmax = newL;
+    return CG_OK;
+}
+
+int read_flags(cg_grid* g, int out[4]) {
+    HIPCHK(g, hipMemcpyAsync(out, g->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    return CG_OK;
+}
+
+int refresh_len_bound(cg_grid* g, unsigned* topq_out) {
+    HIPCHK(g, hipMemsetAsync(g->d_red, 0, 2 * sizeof(unsigned), g->stream));
+    hipLaunchKernelGGL(k_max_top, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_red);
+    unsigned r[2];
+    HIPCHK(g, hipMemcpyAsync(r, g->d_red, sizeof r, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    g->len_bound = (int)r[1];
+    if (topq_out) *topq_out = r[0];
+    return CG_OK;
+}
+
+const uint8_t* mask_ptr(cg_grid* g, int mask_id, bool* ok) {
+    *ok = true;
+    if (mask_id == CG_MASK_NONE) return nullptr;
+    if (mask_id < 0 || (size_t)mask_id >= g->masks.size() || !g->masks[mask_id]) { *ok = false; return nullptr; }
+    return g->masks[mask_id];
+}
+
+void stats_begin(cg_grid* g) {
+    if (g->stats_on) (void)hipMemsetAsync(g->d_stats, 0, CG_NSTAT * sizeof(unsigned long long), g->stream);
+}
+
+void free_kernel(ConfKernel* k) {
+    if (k->d_taps) (void)hipFree(k->d_taps);
+    if (k->d_taps64) (void)hipFree(k->d_taps64);
+    delete k;
+}
+
+// _getConformalKernelArray (script_columngrid.js:324-357) with its 32-entry FIFO cache whose key
+// truncates t, S, dx, dy to 1e-3: two thicknesses closer than that share one kernel.
+ConfKernel* get_kernel(cg_grid* g, double t, double S) {
+    int key[4] = {js_to_int32(t * 1000), js_to_int32(S * 1000), js_to_int32(g->dx * 1000), js_to_int32(g->dy * 1000)};
+    for (ConfKernel* k : g->kcache)
+        if (!memcmp(k->key, key, sizeof key)) return k;
+    ConfKernel* k = new ConfKernel();
+    memcpy(k->key, key, sizeof key);
+    const double dx = g->dx, dy = g->dy;
+    const int Rx = (int)std::ceil(t / dx), Ry = (int)std::ceil(t / dy);
+    const double t2 = t * t, Sinv = 1 / std::max(S, 1e-6), dx2 = dx * dx, dy2 = dy * dy;
+    k->Rx = Rx; k->baseAdd = t;
+    for (int du = -Rx; du <= Rx; du++) {
+        const double du2dx2 = (double)du * du * dx2;
+        for (int dv = -Ry; dv <= Ry; dv++) {
+            const double r2 = du2dx2 + (double)dv * dv * dy2;
+            const double r_lat = std::sqrt(r2) * Sinv;
+            if (r_lat <= t + 1e-9) {
+                const double add = std::sqrt(std::max(0.0, t2 - r_lat * r_lat));
+                k->du.push_back(du); k->dv.push_back(dv); k->add.push_back((float)add);
+            }
+        }
+    }
+    g->kcache.push_back(k);
+    if (g->kcache.size() > 32) { free_kernel(g->kcache.front()); g->kcache.pop_front(); }
+    return k;
+}
+
+// device copies of the taps for the LDS pitch of radius R
+int upload_taps(cg_grid* g, ConfKernel* k, int R) {
+    if (k->dev_R == R) return CG_OK;
+    const int pitch = TJ + 2 * R;
+    std::vector<Tap> safe, fine;
+    for (size_t q = 0; q < k->add.size(); q++) {
+        Tap tp; tp.off = k->du[q] * pitch + k->dv[q]; tp.add = k->add[q];
+        const double scaled = std::ldexp((double)k->add[q], 40);
+        if (scaled == std::floor(scaled)) safe.push_back(tp); else fine.push_back(tp);
+    }
+    if (k->d_taps) { (void)hipFree(k->d_taps); k->d_taps = nullptr; }
+    if (k->d_taps64) { (void)hipFree(k->d_taps64); k->d_taps64 = nullptr; }
+    HIPCHK(g, hipMalloc(&k->d_taps, std::max<size_t>(1, safe.size()) * sizeof(Tap)));
+    HIPCHK(g, hipMalloc(&k->d_taps64, std::max<size_t>(1, fine.size()) * sizeof(Tap)));
+    if (!safe.empty()) HIPCHK(g, hipMemcpy(k->d_taps, safe.data(), safe.size() * sizeof(Tap), hipMemcpyHostToDevice));
+    if (!fine.empty()) HIPCHK(g, hipMemcpy(k->d_taps64, fine.data(), fine.size() * sizeof(Tap), hipMemcpyHostToDevice));
+    k->ntaps = (int)safe.size(); k->ntaps64 = (int)fine.size(); k->dev_R = R;
+    return CG_OK;
+}
+
+int ensure_stencil_scratch(cg_grid* g, int R, bool etch) {
+    size_t need = (size_t)(g->nx + 2 * R) * g->ny;
+    if (need > g->img_cap) {
+        if (g->topq) (void)hipFree(g->topq);
+        if (g->eflag) (void)hipFree(g->eflag);
+        g->topq = nullptr; g->eflag = nullptr; g->img_cap = 0;
+        HIPCHK(g, hipMalloc(&g->topq, need * sizeof(uint16_t)));
+        HIPCHK(g, hipMalloc(&g->eflag, need));
+        g->img_cap = need;
+    }
+    (void)etch;
+    size_t hneed = (size_t)R * g->ny * 3;
+    if (hneed > g->halo_cap) {
+        for (auto& h : g->halo) { if (h) (void)hipFree(h); h = nullptr; }
+        g->halo_cap = 0;
+        for (auto& h : g->halo) HIPCHK(g, hipMalloc(&h, hneed));
+        g->halo_cap = hneed;
+    }
+    return CG_OK;
+}
+
+// vertical deposit with the plane-overflow protocol (see k_depo_vertical)
+int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
+    bool may_overflow = g->len_bound >= g->lmax;
+    if (may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; may_overflow = g->len_bound >= g->lmax; }
+    if (may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
+    const dim3 grid(blocks_for(g->N)), blk(256);
+    if (g->stats_on) hipLaunchKernelGGL(k_depo_vertical<true>, grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
+    else hipLaunchKernelGGL(k_depo_vertical<false>, grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
+    HIPCHK(g, hipGetLastError());
+    if (may_overflow) {
+        int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
+        if (fl[0]) {
+            const int oldL = g->lmax;
+            rc = grow_planes(g); if (rc) return rc;
+            if (g->stats_on) hipLaunchKernelGGL(k_depo_vertical<true>, grid, blk, 0, g->stream, view(g), mask, mat, t, oldL, g->d_flags, g->d_stats);
+            else hipLaunchKernelGGL(k_depo_vertical<false>, grid, blk, 0, g->stream, view(g), mask, mat, t, oldL, g->d_flags, g->d_stats);
+            HIPCHK(g, hipGetLastError());
+        }
+    }
+    if (g->len_bound < 255) g->len_bound += 1;
+    return CG_OK;
+}
+
+int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t_eff, int R, ConfKernel* K, int only_len) {
+    const int tiles = ((g->nx + TI - 1) / TI) * ((g->ny + TJ - 1) / TJ);
+    const size_t lds = stencil_lds_bytes(R);
+    const dim3 grid(tiles), blk(256);
+#define LAUNCH(E, S)                                                                                           \
+    do {                                                                                                       \
+        if (lds > 48 * 1024)                                                                                   \
+            HIPCHK(g, hipFuncSetAttribute((const void*)k_stencil_apply<E, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_stencil_apply<E, S>), grid, blk, lds, g->stream, view(g), mask, mat, t_eff, R, g->topq, g->eflag, \
+                           K->d_taps, K->ntaps, K->d_taps64, K->ntaps64, only_len, g->d_flags, g->d_stats);    \
+    } while (0)
+    if (etch) { if (g->stats_on) LAUNCH(true, true); else LAUNCH(true, false); }
+    else { if (g->stats_on) LAUNCH(false, true); else LAUNCH(false, false); }
+#undef LAUNCH
+    HIPCHK(g, hipGetLastError());
+    return CG_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* cg_version(void) { return "colgrid 0.1 gfx950"; }
+
+const char* cg_last_error(const cg_grid* g) { return g ? g->err.c_str() : t_create_error.c_str(); }
+
+int cg_create_slab(int nx_global, int ny, int i0, int nx_local, double dx, double dy, int lmax_init, double zscale,
+                   cg_grid** out) {
+    if (!out) return fail(nullptr, CG_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (nx_global < 1 || ny < 1 || nx_local < 1 || i0 < 0 || i0 + nx_local > nx_global || !(dx > 0) || !(dy > 0) || !(zscale > 0))
+        return fail(nullptr, CG_ERR_ARG, "bad domain: nx_global=%d ny=%d i0=%d nx_local=%d dx=%g dy=%g zscale=%g", nx_global, ny, i0,
+                    nx_local, dx, dy, zscale);
+    cg_grid* g = new cg_grid();
+    hipError_t e = hipGetDevice(&g->device);
+    if (e != hipSuccess) { int rc = fail(nullptr, CG_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e)); delete g; return rc; }
+    g->nx = nx_local; g->ny = ny; g->nx_global = nx_global; g->i0 = i0;
+    g->N = (size_t)nx_local * ny; g->dx = dx; g->dy = dy; g->zscale = zscale;
+    int lmax = next_pow2(lmax_init);
+    if (lmax > 256) lmax = 256;
+    int rc = CG_OK;
+    auto body = [&]() -> int {
+        HIPCHK(g, hipStreamCreateWithFlags(&g->own_stream, hipStreamNonBlocking));
+        g->stream = g->own_stream;
+        HIPCHK(g, hipMalloc(&g->d_flags, 4 * sizeof(int)));
+        HIPCHK(g, hipMalloc(&g->d_red, 4 * sizeof(unsigned)));
+        HIPCHK(g, hipMalloc(&g->d_sum, sizeof(unsigned long long)));
+        HIPCHK(g, hipMalloc(&g->d_stats, CG_NSTAT * sizeof(unsigned long long)));
+        HIPCHK(g, hipMemset(g->d_flags, 0, 4 * sizeof(int)));
+        HIPCHK(g, hipMemset(g->d_stats, 0, CG_NSTAT * sizeof(unsigned long long)));
+        HIPCHK(g, hipEventCreate(&g->ev0)); HIPCHK(g, hipEventCreate(&g->ev1));
+        int r = alloc_planes(g, lmax); if (r) return r;
+        r = zero_planes(g); if (r) return r;
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        return CG_OK;
+    };
+    rc = body();
+    if (rc) { t_create_error = g->err; cg_destroy(g); return rc; }
+    *out = g;
+    return CG_OK;
+}
+
+int cg_create(double lx, double ly, double dx, double dy, int lmax_init, double zscale, cg_grid** out) {
+    if (!(dx > 0) || !(dy > 0)) return fail(nullptr, CG_ERR_ARG, "bad pitch dx=%g dy=%g", dx, dy);
+    // setDomain (script_columngrid.js:49-60)
+    double nx = js_round(lx / dx), ny = js_round(ly / dy);
+    int NX = nx < 1 ? 1 : (int)nx, NY = ny < 1 ? 1 : (int)ny;
+    return cg_create_slab(NX, NY, 0, NX, dx, dy, lmax_init, zscale, out);
+}
+
+int cg_destroy(cg_grid* g) {
+    if (!g) return CG_OK;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    free_planes(g);
+    for (auto m : g->masks) if (m) (void)hipFree(m);
+    for (auto k : g->kcache) free_kernel(k);
+    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.mat); (void)hipFree(s.second.z0); (void)hipFree(s.second.z1); }
+    if (g->topq) (void)hipFree(g->topq);
+    if (g->eflag) (void)hipFree(g->eflag);
+    for (auto h : g->halo) if (h) (void)hipFree(h);
+    if (g->d_flags) (void)hipFree(g->d_flags);
+    if (g->d_red) (void)hipFree(g->d_red);
+    if (g->d_sum) (void)hipFree(g->d_sum);
+    if (g->d_stats) (void)hipFree(g->d_stats);
+    if (g->sl_mat) (void)hipFree(g->sl_mat);
+    if (g->sl_zp) (void)hipFree(g->sl_zp);
+    if (g->sl_len) (void)hipFree(g->sl_len);
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->own_stream) (void)hipStreamDestroy(g->own_stream);
+    delete g;
+    return CG_OK;
+}
+
+int cg_reset(cg_grid* g, int lmax_init) {
+    NEED(g);
+    int lmax = next_pow2(lmax_init > 0 ? lmax_init : g->lmax);
+    if (lmax > 256) lmax = 256;
+    g->pend.active = false;
+    if (lmax != g->lmax) {
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        int rc = alloc_planes(g, lmax); if (rc) return rc;
+    }
+    return zero_planes(g);
+}
+
+int cg_clear(cg_grid* g) { NEED(g); g->pend.active = false; return zero_planes(g); }
+
+int cg_get_info(const cg_grid* g, cg_info* o) {
+    if (!g || !o) return CG_ERR_ARG;
+    o->nx = g->nx; o->ny = g->ny; o->nx_global = g->nx_global; o->i0 = g->i0; o->lmax = g->lmax; o->device = g->device;
+    o->dx = g->dx; o->dy = g->dy; o->zscale = g->zscale;
+    o->offset_x = -(g->nx_global - 1) * g->dx / 2; o->offset_y = -(g->ny - 1) * g->dy / 2;
+    o->lx_eff = g->nx_global * g->dx; o->ly_eff = g->ny * g->dy;
+    return CG_OK;
+}
+
+int cg_set_stream(cg_grid* g, void* s) {
+    NEED(g);
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    g->stream = s ? (hipStream_t)s : g->own_stream;
+    return CG_OK;
+}
+
+int cg_sync(cg_grid* g) { NEED(g); HIPCHK(g, hipStreamSynchronize(g->stream)); return CG_OK; }
+
+// ---- masks ----------------------------------------------------------------------------------
+static int new_mask_slot(cg_grid* g, uint8_t** buf, int* id) {
+    HIPCHK(g, hipMalloc(buf, std::max<size_t>(g->N, 1)));
+    for (size_t k = 0; k < g->masks.size(); k++)
+        if (!g->masks[k]) { g->masks[k] = *buf; *id = (int)k; return CG_OK; }
+    g->masks.push_back(*buf); *id = (int)g->masks.size() - 1;
+    return CG_OK;
+}
+
+int cg_mask_from_raster(cg_grid* g, const uint8_t* host, size_t n, int* mask_id) {
+    NEED(g);
+    if (!host || !mask_id || n != g->N) return fail(g, CG_ERR_ARG, "mask raster: need %zu bytes, got %zu", g->N, n);
+    uint8_t* buf; int rc = new_mask_slot(g, &buf, mask_id); if (rc) return rc;
+    HIPCHK(g, hipMemcpyAsync(buf, host, n, hipMemcpyHostToDevice, g->stream));
+    hipLaunchKernelGGL(k_mask_normalise, dim3(blocks_for(n)), dim3(256), 0, g->stream, buf, buf, n);
+    HIPCHK(g, hipStreamSynchronize(g->stream));      // the host buffer is the caller's again
+    return CG_OK;
+}
+
+int cg_mask_from_device_raster(cg_grid* g, const void* dev, size_t n, int* mask_id) {
+    NEED(g);
+    if (!dev || !mask_id || n != g->N) return fail(g, CG_ERR_ARG, "mask raster: need %zu bytes, got %zu", g->N, n);
+    uint8_t* buf; int rc = new_mask_slot(g, &buf, mask_id); if (rc) return rc;
+    hipLaunchKernelGGL(k_mask_normalise, dim3(blocks_for(n)), dim3(256), 0, g->stream, (const uint8_t*)dev, buf, n);
+    HIPCHK(g, hipGetLastError());
+    return CG_OK;
+}
+
+int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const double* pts, int npts, int* mask_id) {
+    NEED(g);
+    if (!mask_id || nshapes < 0 || npts < 0 || (nshapes > 0 && !shapes) || (npts > 0 && !pts))
+        return fail(g, CG_ERR_ARG, "bad shape list");
+    for (int s = 0; s < nshapes; s++)
+        if (shapes[s].type == CG_SHAPE_POLYGON && (shapes[s].pt_off < 0 || shapes[s].pt_cnt < 0 || shapes[s].pt_off + shapes[s].pt_cnt > npts))
+            return fail(g, CG_ERR_ARG, "shape %d: polygon points [%d,+%d) outside the %d given", s, shapes[s].pt_off, shapes[s].pt_cnt, npts);
+    static_assert(sizeof(Shape) == sizeof(cg_shape), "Shape mirrors cg_shape");
+    uint8_t* buf; int rc = new_mask_slot(g, &buf, mask_id); if (rc) return rc;
+    Shape* d_sh = nullptr; double* d_pts = nullptr;
+    HIPCHK(g, hipMalloc(&d_sh, std::max(1, nshapes) * sizeof(Shape)));
+    HIPCHK(g, hipMalloc(&d_pts, std::max(1, npts) * 2 * sizeof(double)));
+    if (nshapes) HIPCHK(g, hipMemcpyAsync(d_sh, shapes, nshapes * sizeof(Shape), hipMemcpyHostToDevice, g->stream));
+    if (npts) HIPCHK(g, hipMemcpyAsync(d_pts, pts, (size_t)npts * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    hipLaunchKernelGGL(k_mask_shapes, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, g->nx, g->ny, g->i0, g->dx, g->dy, d_sh, nshapes,
+                       d_pts, buf);
+    HIPCHK(g, hipGetLastError());
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    (void)hipFree(d_sh); (void)hipFree(d_pts);
+    return CG_OK;
+}
+
+int cg_mask_download(cg_grid* g, int mask_id, uint8_t* out, size_t n) {
+    NEED(g);
+    bool ok; const uint8_t* m = mask_ptr(g, mask_id, &ok);
+    if (!ok || !m || !out || n != g->N) return fail(g, CG_ERR_ARG, "bad mask id %d or size", mask_id);
+    HIPCHK(g, hipMemcpyAsync(out, m, n, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    return CG_OK;
+}
+
+int cg_mask_destroy(cg_grid* g, int mask_id) {
+    NEED(g);
+    bool ok; const uint8_t* m = mask_ptr(g, mask_id, &ok);
+    if (!ok || !m) return fail(g, CG_ERR_ARG, "bad mask id %d", mask_id);
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    (void)hipFree(g->masks[mask_id]); g->masks[mask_id] = nullptr;
+    return CG_OK;
+}
+
+// ---- steps ----------------------------------------------------------------------------------
+int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thickness, double conformality, int has_lower, int has_upper,
+                     int* radius_rows) {
+    NEED(g);
+    if (radius_rows) *radius_rows = 0;
+    if (kind != CG_STENCIL_DEPOSIT && kind != CG_STENCIL_ETCH) return fail(g, CG_ERR_ARG, "bad stencil kind %d", kind);
+    if (g->pend.active) return fail(g, CG_ERR_STATE, "a stencil step is already open");
+    bool ok; const uint8_t* mask = mask_ptr(g, mask_id, &ok);
+    if (!ok) return fail(g, CG_ERR_ARG, "unknown mask id %d", mask_id);
+    if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
+    if (std::isnan(thickness) || std::isnan(conformality)) return fail(g, CG_ERR_ARG, "NaN thickness or conformality");
+    const double t = std::max(0.0, thickness);
+    if (!(t > 0)) return CG_OK;                                           // cg1:437, 600
+    const double S = std::max(0.0, std::min(1.0, conformality));          // cg1:440, 603
+    const double latRange = t * S;
+    stats_begin(g);
+    if (latRange < std::min(g->dx, g->dy)) {                              // cg1:445, 609
+        if (kind == CG_STENCIL_DEPOSIT) return run_depo_vertical(g, mask, mat, t);
+        const dim3 grid(blocks_for(g->N)), blk(256);
+        if (g->stats_on) hipLaunchKernelGGL(k_etch_vertical<true>, grid, blk, 0, g->stream, view(g), mask, mat, t, g->d_stats);
+        else hipLaunchKernelGGL(k_etch_vertical<false>, grid, blk, 0, g->stream, view(g), mask, mat, t, g->d_stats);
+        HIPCHK(g, hipGetLastError());
+        return CG_OK;
+    }
+    if (g->dx != g->dy)
+        return fail(g, CG_ERR_UNSUPPORTED, "lateral steps need dx == dy (the reference pads the height map with Rx in both directions, "
+                                            "script_columngrid.js:471, 666)");
+    ConfKernel* K = get_kernel(g, t, S);
+    const int R = K->Rx;
+    if (stencil_lds_bytes(R) > 160 * 1024) return fail(g, CG_ERR_UNSUPPORTED, "stencil radius %d cells does not fit the LDS tile", R);
+    if ((has_lower || has_upper) && g->nx < R)
+        return fail(g, CG_ERR_UNSUPPORTED, "slab of %d rows is thinner than the stencil radius %d", g->nx, R);
+    int rc = ensure_stencil_scratch(g, R, kind == CG_STENCIL_ETCH); if (rc) return rc;
+    rc = upload_taps(g, K, R); if (rc) return rc;
+    const dim3 grid(blocks_for(g->N)), blk(256);
+    if (kind == CG_STENCIL_ETCH) {
+        HIPCHK(g, hipMemsetAsync(g->d_flags + 1, 0, sizeof(int), g->stream));
+        hipLaunchKernelGGL(k_snapshot_tops<true>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag, g->d_flags);
+    } else {
+        hipLaunchKernelGGL(k_snapshot_tops<false>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag, g->d_flags);
+    }
+    HIPCHK(g, hipGetLastError());
+    if (has_lower || has_upper) {
+        hipLaunchKernelGGL(k_halo_pack, dim3(blocks_for((size_t)R * g->ny)), blk, 0, g->stream, g->topq,
+                           kind == CG_STENCIL_ETCH ? g->eflag : (const uint8_t*)nullptr, g->nx, g->ny, R, g->halo[0], g->halo[1]);
+        HIPCHK(g, hipGetLastError());
+    }
+    g->pend.active = true; g->pend.kind = kind; g->pend.mask_id = mask_id; g->pend.mat = mat; g->pend.R = R; g->pend.K = K;
+    g->pend.t_eff = (kind == CG_STENCIL_DEPOSIT) ? K->baseAdd : t;        // cg1:470/499 vs cg1:702
+    g->pend.has_lower = has_lower != 0; g->pend.has_upper = has_upper != 0;
+    if (radius_rows) *radius_rows = R;
+    return CG_OK;
+}
+
+int cg_halo_buffers(cg_grid* g, void** send_lower, void** send_upper, void** recv_lower, void** recv_upper, size_t* bytes_each) {
+    NEED(g);
+    if (!g->pend.active) return fail(g, CG_ERR_STATE, "no stencil step is open");
+    if (send_lower) *send_lower = g->halo[0];
+    if (send_upper) *send_upper = g->halo[1];
+    if (recv_lower) *recv_lower = g->halo[2];
+    if (recv_upper) *recv_upper = g->halo[3];
+    if (bytes_each) *bytes_each = (size_t)g->pend.R * g->ny * 3;
+    return CG_OK;
+}
+
+int cg_stencil_finish(cg_grid* g) {
+    NEED(g);
+    if (!g->pend.active) return fail(g, CG_ERR_STATE, "no stencil step is open");
+    Pending p = g->pend;
+    g->pend.active = false;
+    bool ok; const uint8_t* mask = mask_ptr(g, p.mask_id, &ok);
+    if (!ok) return fail(g, CG_ERR_ARG, "mask %d vanished during the step", p.mask_id);
+    const bool etch = p.kind == CG_STENCIL_ETCH;
+    hipLaunchKernelGGL(k_halo_unpack, dim3(blocks_for((size_t)p.R * g->ny)), dim3(256), 0, g->stream, g->topq,
+                       etch ? g->eflag : (uint8_t*)nullptr, g->nx, g->ny, p.R, p.has_lower ? g->halo[2] : (const uint8_t*)nullptr,
+                       p.has_upper ? g->halo[3] : (const uint8_t*)nullptr);
+    HIPCHK(g, hipGetLastError());
+    if (etch) return launch_stencil(g, true, mask, p.mat, p.t_eff, p.R, p.K, -1);
+
+    bool may_overflow = g->len_bound >= g->lmax;
+    if (may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; may_overflow = g->len_bound >= g->lmax; }
+    if (may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
+    int rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1); if (rc) return rc;
+    if (may_overflow) {
+        int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
+        if (fl[0]) {
+            const int oldL = g->lmax;
+            rc = grow_planes(g); if (rc) return rc;
+            rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, oldL); if (rc) return rc;
+        }
+    }
+    if (g->len_bound < 255) g->len_bound += 1;
+    // identify_cavity (cg1:543) -- a no-op while no column has a vertical gap
+    if (g->has_gaps) return cg_identify_cavity(g);
+    return CG_OK;
+}
+
+int cg_deposit_general(cg_grid* g, int mask_id, int mat, double thickness, double conformality) {
+    int R = 0;
+    int rc = cg_stencil_begin(g, CG_STENCIL_DEPOSIT, mask_id, mat, thickness, conformality, 0, 0, &R);
+    if (rc || !g->pend.active) return rc;
+    return cg_stencil_finish(g);
+}
+
+int cg_etch_general(cg_grid* g, int mask_id, int mat, double thickness, double conformality) {
+    int R = 0;
+    int rc = cg_stencil_begin(g, CG_STENCIL_ETCH, mask_id, mat, thickness, conformality, 0, 0, &R);
+    if (rc || !g->pend.active) return rc;
+    return cg_stencil_finish(g);
+}
+
+int cg_cmp(cg_grid* g, double depth, int stop_mat) {
+    NEED(g); (void)depth; (void)stop_mat;
+    return fail(g, CG_ERR_UNSUPPORTED, "cmp is not built yet");
+}
+
+int cg_strip_connected(cg_grid* g, int mat) {
+    NEED(g); (void)mat;
+    return fail(g, CG_ERR_UNSUPPORTED, "strip_connected is not built yet");
+}
+
+int cg_identify_cavity(cg_grid* g) {
+    NEED(g);
+    // With no vertical gap anywhere every inserted cavity piece is a column-top piece, hence
+    // exposed, hence stripped again (script_columngrid2.js:60-67, script_columngrid.js:891):
+    // the grid is left exactly as it was.
+    if (!g->has_gaps) return CG_OK;
+    return fail(g, CG_ERR_UNSUPPORTED, "identify_cavity on a grid with vertical gaps is not built yet");
+}
+
+int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q) {
+    NEED(g);
+    unsigned q = 0;
+    int rc = refresh_len_bound(g, &q); if (rc) return rc;
+    if (top_q) *top_q = q;
+    if (z_nm) { double z = (double)q * g->zscale; *z_nm = z > 0 ? z : 1; }      // cg2:103
+    return CG_OK;
+}
+
+// ---- host exchange --------------------------------------------------------------------------
+int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
+    NEED(g);
+    if (!mat || !zpair || !len) return fail(g, CG_ERR_ARG, "null output array");
+    const int L = g->lmax;
+    const size_t chunk = std::min<size_t>(g->N, (size_t)1 << 20);
+    uint8_t *dm = nullptr, *dl = nullptr; uint16_t* dz = nullptr;
+    HIPCHK(g, hipMalloc(&dm, chunk * L)); HIPCHK(g, hipMalloc(&dz, chunk * L * 4)); HIPCHK(g, hipMalloc(&dl, chunk));
+    for (size_t c0 = 0; c0 < g->N; c0 += chunk) {
+        size_t n = std::min(chunk, g->N - c0);
+        hipLaunchKernelGGL(k_gather_columns, dim3(blocks_for(n * L)), dim3(256), 0, g->stream, view(g), c0, (size_t)1, n, L, dm, dz, dl);
+        HIPCHK(g, hipGetLastError());
+        HIPCHK(g, hipMemcpyAsync(mat + c0 * L, dm, n * L, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipMemcpyAsync(zpair + 2 * c0 * L, dz, n * L * 4, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipMemcpyAsync(len + c0, dl, n, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+    }
+    (void)hipFree(dm); (void)hipFree(dz); (void)hipFree(dl);
+    return CG_OK;
+}
+
+int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8_t* len, int lmax) {
+    NEED(g);
+    if (!mat || !zpair || !len || lmax < 1 || lmax > 256) return fail(g, CG_ERR_ARG, "bad upload arguments (lmax=%d)", lmax);
+    g->pend.active = false;
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    if (lmax != g->lmax) { int rc = alloc_planes(g, lmax); if (rc) return rc; }
+    const int L = lmax;
+    const size_t chunk = std::min<size_t>(g->N, (size_t)1 << 20);
+    uint8_t *dm = nullptr, *dl = nullptr; uint16_t* dz = nullptr;
+    HIPCHK(g, hipMalloc(&dm, chunk * L)); HIPCHK(g, hipMalloc(&dz, chunk * L * 4)); HIPCHK(g, hipMalloc(&dl, chunk));
+    HIPCHK(g, hipMemsetAsync(g->d_flags + 2, 0, sizeof(int), g->stream));
+    for (size_t c0 = 0; c0 < g->N; c0 += chunk) {
+        size_t n = std::min(chunk, g->N - c0);
+        HIPCHK(g, hipMemcpyAsync(dm, mat + c0 * L, n * L, hipMemcpyHostToDevice, g->stream));
+        HIPCHK(g, hipMemcpyAsync(dz, zpair + 2 * c0 * L, n * L * 4, hipMemcpyHostToDevice, g->stream));
+        HIPCHK(g, hipMemcpyAsync(dl, len + c0, n, hipMemcpyHostToDevice, g->stream));
+        hipLaunchKernelGGL(k_scatter_columns, dim3(blocks_for(n * L)), dim3(256), 0, g->stream, view(g), c0, n, L, dm, dz, dl, g->d_flags);
+        HIPCHK(g, hipGetLastError());
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+    }
+    (void)hipFree(dm); (void)hipFree(dz); (void)hipFree(dl);
+    int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
+    g->has_gaps = fl[2] != 0;
+    g->len_bound = 255;            // refreshed lazily when it matters
+    return CG_OK;
+}
+
+int cg_snapshot_save(cg_grid* g, int slot) {
+    NEED(g);
+    if (slot < 0) return fail(g, CG_ERR_ARG, "bad snapshot slot %d", slot);
+    cg_snapshot_drop(g, slot);
+    Snapshot s; size_t S = g->N * (size_t)g->lmax;
+    HIPCHK(g, hipMalloc(&s.len, g->N)); HIPCHK(g, hipMalloc(&s.mat, S)); HIPCHK(g, hipMalloc(&s.z0, 2 * S)); HIPCHK(g, hipMalloc(&s.z1, 2 * S));
+    HIPCHK(g, hipMemcpyAsync(s.len, g->len, g->N, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(s.mat, g->mat, S, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(s.z0, g->z0, 2 * S, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(s.z1, g->z1, 2 * S, hipMemcpyDeviceToDevice, g->stream));
+    s.lmax = g->lmax; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps;
+    g->snaps[slot] = s;
+    return CG_OK;
+}
+
+int cg_snapshot_load(cg_grid* g, int slot) {
+    NEED(g);
+    auto it = g->snaps.find(slot);
+    if (it == g->snaps.end()) return fail(g, CG_ERR_ARG, "no snapshot in slot %d", slot);
+    const Snapshot& s = it->second;
+    g->pend.active = false;
+    if (s.lmax != g->lmax) { HIPCHK(g, hipStreamSynchronize(g->stream)); int rc = alloc_planes(g, s.lmax); if (rc) return rc; }
+    size_t S = g->N * (size_t)g->lmax;
+    HIPCHK(g, hipMemcpyAsync(g->len, s.len, g->N, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(g->mat, s.mat, S, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(g->z0, s.z0, 2 * S, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(g->z1, s.z1, 2 * S, hipMemcpyDeviceToDevice, g->stream));
+    g->len_bound = s.len_bound; g->has_gaps = s.has_gaps;
+    return CG_OK;
+}
+
+int cg_snapshot_drop(cg_grid* g, int slot) {
+    NEED(g);
+    auto it = g->snaps.find(slot);
+    if (it == g->snaps.end()) return CG_OK;
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    (void)hipFree(it->second.len); (void)hipFree(it->second.mat); (void)hipFree(it->second.z0); (void)hipFree(it->second.z1);
+    g->snaps.erase(it);
+    return CG_OK;
+}
+
+int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count, void** d_mat, void** d_zpair, void** d_len) {
+    NEED(g);
+    if ((axis != 0 && axis != 1) || !index || count < 1) return fail(g, CG_ERR_ARG, "bad slice request");
+    const size_t line = axis == 0 ? (size_t)g->ny : (size_t)g->nx;
+    const int L = g->lmax;
+    const size_t need = line * count;
+    for (int s = 0; s < count; s++) {
+        const int lim = axis == 0 ? g->nx : g->ny;
+        if (index[s] < 0 || index[s] >= lim) return fail(g, CG_ERR_ARG, "slice index %d outside [0,%d)", index[s], lim);
+    }
+    if (need * L > g->sl_cap) {
+        if (g->sl_mat) (void)hipFree(g->sl_mat);
+        if (g->sl_zp) (void)hipFree(g->sl_zp);
+        if (g->sl_len) (void)hipFree(g->sl_len);
+        g->sl_mat = nullptr; g->sl_zp = nullptr; g->sl_len = nullptr; g->sl_cap = 0;
+        HIPCHK(g, hipMalloc(&g->sl_mat, need * L)); HIPCHK(g, hipMalloc(&g->sl_zp, need * L * 4)); HIPCHK(g, hipMalloc(&g->sl_len, need));
+        g->sl_cap = need * L;
+    }
+    for (int s = 0; s < count; s++) {
+        size_t col0 = axis == 0 ? (size_t)index[s] * g->ny : (size_t)index[s];
+        size_t stride = axis == 0 ? 1 : (size_t)g->ny;
+        hipLaunchKernelGGL(k_gather_columns, dim3(blocks_for(line * L)), dim3(256), 0, g->stream, view(g), col0, stride, line, L,
+                           g->sl_mat + s * line * L, g->sl_zp + 2 * s * line * L, g->sl_len + s * line);
+    }
+    HIPCHK(g, hipGetLastError());
+    if (d_mat) *d_mat = g->sl_mat;
+    if (d_zpair) *d_zpair = g->sl_zp;
+    if (d_len) *d_len = g->sl_len;
+    return CG_OK;
+}
+
+int cg_slices(cg_grid* g, int axis, const int32_t* index, int count, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
+    if (!mat || !zpair || !len) return fail(g, CG_ERR_ARG, "null output array");
+    int rc = cg_slices_device(g, axis, index, count, nullptr, nullptr, nullptr); if (rc) return rc;
+    const size_t line = axis == 0 ? (size_t)g->ny : (size_t)g->nx;
+    const size_t n = line * count; const int L = g->lmax;
+    HIPCHK(g, hipMemcpyAsync(mat, g->sl_mat, n * L, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(g, hipMemcpyAsync(zpair, g->sl_zp, n * L * 4, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(g, hipMemcpyAsync(len, g->sl_len, n, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    return CG_OK;
+}
+
+int cg_index_from_pos(const cg_grid* g, int axis, double pos, int32_t* index) {
+    if (!g || !index || (axis != 0 && axis != 1)) return CG_ERR_ARG;
+    const int n = axis == 0 ? g->nx_global : g->ny;
+    const double pitch = axis == 0 ? g->dx : g->dy;
+    const double off = -(n - 1) * pitch / 2;
+    double r = js_round((pos - off) / pitch);
+    if (r < 0) r = 0;
+    if (r > n - 1) r = n - 1;
+    if (std::isnan(r)) r = 0;
+    *index = (int32_t)r;
+    return CG_OK;
+}
+
+// ---- checks and measurement -----------------------------------------------------------------
+int cg_checksum(cg_grid* g, uint64_t* sum) {
+    NEED(g);
+    if (!sum) return fail(g, CG_ERR_ARG, "null output");
+    HIPCHK(g, hipMemsetAsync(g->d_sum, 0, sizeof(unsigned long long), g->stream));
+    hipLaunchKernelGGL(k_checksum, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_sum);
+    HIPCHK(g, hipGetLastError());
+    unsigned long long h = 0;
+    HIPCHK(g, hipMemcpyAsync(&h, g->d_sum, sizeof h, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    *sum = h;
+    return CG_OK;
+}
+
+int cg_step_stats(cg_grid* g, int enable, uint64_t stats[CG_NSTAT]) {
+    NEED(g);
+    if (stats) {
+        unsigned long long h[CG_NSTAT];
+        HIPCHK(g, hipMemcpyAsync(h, g->d_stats, sizeof h, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        for (int q = 0; q < CG_NSTAT; q++) stats[q] = h[q];
+        stats[0] = g->N;
+    }
+    g->stats_on = enable != 0;
+    return CG_OK;
+}
+
+int cg_timer_start(cg_grid* g) { NEED(g); HIPCHK(g, hipEventRecord(g->ev0, g->stream)); return CG_OK; }
+
+int cg_timer_stop(cg_grid* g, float* ms) {
+    NEED(g);
+    HIPCHK(g, hipEventRecord(g->ev1, g->stream));
+    HIPCHK(g, hipEventSynchronize(g->ev1));
+    float v = 0; HIPCHK(g, hipEventElapsedTime(&v, g->ev0, g->ev1));
+    if (ms) *ms = v;
+    return CG_OK;
+}
+
+}  // extern "C"

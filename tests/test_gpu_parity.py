@@ -1,0 +1,188 @@
+"""HIP engine (through the C ABI) against the reference's golden outputs and the CPU oracle.
+
+Bit-exact bar: len / mat / zpair arrays must be identical, dead slots included.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN, STEP_CASES, load_case, fnv_bytes, run_steps
+from oracle import OracleGrid
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine():
+    import fem_amd
+    return fem_amd
+
+
+def _grid_for(case):
+    d = case["domain"]
+    return _engine().ColumnGrid(d["LX"], d["LY"], d["dx"], d["dy"], d.get("Lmax", 32), d.get("zScale", 0.1))
+
+
+def _assert_same(g, ref_arrays, what):
+    ln, mat, zp = g.download()
+    rl, rm, rz = ref_arrays
+    np.testing.assert_array_equal(ln, rl, err_msg=what + " len")
+    np.testing.assert_array_equal(mat, rm, err_msg=what + " mat")
+    np.testing.assert_array_equal(zp, rz, err_msg=what + " zpair")
+
+
+@pytest.mark.parametrize("name", STEP_CASES)
+def test_golden_steps(name):
+    case = load_case(name)
+    g = _grid_for(case)
+    assert (g.NX, g.NY) == (case["nx"], case["ny"])
+    n = g.NX * g.NY
+    masks = {}
+
+    def mask_of(m):
+        if m not in masks:
+            masks[m] = g.mask_from_raster(np.ones(n, np.uint8)) if m == "all" else g.mask_from_shapes(case["reduced"][m])
+        return masks[m]
+
+    small = n <= 16384
+
+    def check(idx, s):
+        assert g.Lmax == s["lmax"], f"{name} step {idx}"
+        assert g.maxHeight() == s["max_height"], f"{name} step {idx}"
+        if "dump_index" in s:
+            ln, mat, zp, lm = case["dump_arrays"][s["dump_index"]]
+            _assert_same(g, (ln, mat, zp), f"{name} step {idx} {s['op']}")
+        if small or idx == len(case["steps"]) - 1:
+            assert g.fnv() == s["fnv"], f"{name} step {idx} {s['op']}"
+
+    run_steps(g, case, mask_of, check)
+    g.close()
+
+
+@pytest.mark.parametrize("name", [c for c in STEP_CASES if c != "anchor_256"])
+def test_golden_mask_rasters(name):
+    case = load_case(name)
+    g = _grid_for(case)
+    for m in case["mask_order"]:
+        got = g.mask_from_shapes(case["reduced"][m]).download()
+        np.testing.assert_array_equal(got, case["rasters"][m], err_msg=f"{name} mask {m}")
+    g.close()
+
+
+@pytest.mark.parametrize("nx", [64, 256])
+def test_runtime_c1_golden(nx):
+    with open(os.path.join(GOLDEN, f"runtime_c1_{nx}.json")) as f:
+        c = json.load(f)
+    d = c["domain"]
+    g = _engine().ColumnGrid(d["LX"], d["LY"], d["dx"], d["dy"])
+    m = g.mask_from_shapes(c["reduced"])
+    raster = m.download()
+    assert int(raster.sum()) == c["open_cells"] and fnv_bytes(raster) == c["raster_fnv"]
+    ids = {k: v["id"] for k, v in c["materialColor"].items()}
+    for p in c["processes"]:
+        mask = None if p["mask"] == "-" else m
+        S = p.get("conformality", 0) if p["kind"] != "SUBSTR" else 0
+        if p["kind"] in ("SUBSTR", "DEPO"):
+            g.deposit_general(mask, ids[p["material"]], p["thickness"], S)
+        else:
+            g.etch_general(mask, ids[p["material"]], p["thickness"], S)
+    assert g.fnv() == c["fnv"]
+    g.close()
+
+
+def _lcg(seed):
+    s = seed
+    while True:
+        s = (s * 1103515245 + 12345) & 0x7FFFFFFF
+        yield s
+
+
+def _random_mask_data(rng, L, nshapes):
+    objs = []
+    for _ in range(nshapes):
+        kind = next(rng) % 4
+        left, top = next(rng) % L, next(rng) % L
+        w, h = 4 + next(rng) % (L // 3), 4 + next(rng) % (L // 3)
+        ang = [0, 0, 15, 30, -40, 77.5][next(rng) % 6]
+        pol = "negative" if next(rng) % 3 == 0 else "positive"
+        o = {"left": left, "top": top, "width": w, "height": h, "angle": ang, "scaleX": 1, "scaleY": 1,
+             "visible": True, "data": {"polarity": pol}}
+        if kind == 0:
+            o["type"] = "rect"
+        elif kind == 1:
+            o.update(type="circle", radius=w / 2, height=w)
+        elif kind == 2:
+            o.update(type="ellipse", rx=w / 2, ry=h / 2)
+        else:
+            o.update(type="polygon", points=[{"x": 0, "y": 0}, {"x": w, "y": h / 3}, {"x": w / 2, "y": h}, {"x": -w / 4, "y": h / 2}])
+        objs.append(o)
+    return {"objects": objs}
+
+
+@pytest.mark.parametrize("nx,ny,seed", [(192, 320, 1), (333, 257, 2), (512, 512, 3)])
+def test_random_flow_vs_oracle(nx, ny, seed):
+    """A seeded multi-step flow with every supported step kind on grids the oracle does in seconds."""
+    fem = _engine()
+    rng = _lcg(seed)
+    L = 2 * max(nx, ny)
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    masks = []
+    for _ in range(3):
+        red = fem.reduce_mask(_random_mask_data(rng, L, 12))
+        gm = g.mask_from_shapes(red)
+        om = o.mask_raster(red)
+        np.testing.assert_array_equal(gm.download(), om)
+        masks.append((gm, om))
+    g.stats_enable(True)
+    steps = [("d", None, 3, 30, 0), ("d", None, 4, 20, 0)]
+    for k in range(14):
+        kind = "d" if next(rng) % 2 == 0 else "e"
+        mi = next(rng) % 4
+        mat = [3, 4, 5, 6, 255][next(rng) % (5 if kind == "e" else 4)]
+        t = [2.5, 4, 6, 7.3, 10, 13.05, 21][next(rng) % 7]
+        S = [0, 0, 0.5, 0.85, 1.0][next(rng) % 5]
+        steps.append((kind, mi if mi < 3 else None, mat, t, S))
+    for idx, (kind, mi, mat, t, S) in enumerate(steps):
+        gm, om = (None, None) if mi is None else masks[mi]
+        if kind == "d":
+            g.deposit_general(gm, mat, t, S); o.deposit_general(om, mat, t, S)
+        else:
+            g.etch_general(gm, mat, t, S); o.etch_general(om, mat, t, S)
+        assert g.checksum() == o.checksum(), f"step {idx} {kind} mat={mat} t={t} S={S} mask={mi}"
+        gs, os_ = g.stats(), o.stats()
+        assert gs[2:6] == os_[2:6], f"step {idx} stats {gs} vs {os_}"
+    assert g.Lmax == o.Lmax
+    _assert_same(g, o.arrays(), "final")
+    g.close()
+
+
+def test_upload_download_roundtrip_and_slices():
+    fem = _engine()
+    case = load_case("stencil_small")
+    ln, mat, zp, lm = case["dump_arrays"][-1]
+    g = _grid_for(case)
+    g.upload(ln, mat, zp, lm)
+    _assert_same(g, (ln, mat, zp), "roundtrip")
+    nx, ny = case["nx"], case["ny"]
+    M = mat.reshape(nx, ny, lm); Z = zp.reshape(nx, ny, lm, 2); Ln = ln.reshape(nx, ny)
+    sl, sm, sz = g.slices("YZ", [0, 5, nx - 1])
+    for s, i in enumerate([0, 5, nx - 1]):
+        np.testing.assert_array_equal(sl[s], Ln[i]); np.testing.assert_array_equal(sm[s], M[i]); np.testing.assert_array_equal(sz[s], Z[i])
+    sl, sm, sz = g.slices("XZ", [3, ny - 1])
+    for s, j in enumerate([3, ny - 1]):
+        np.testing.assert_array_equal(sl[s], Ln[:, j]); np.testing.assert_array_equal(sm[s], M[:, j]); np.testing.assert_array_equal(sz[s], Z[:, j])
+    # snapshots
+    g.snapshot_save(7)
+    g.etch_general(None, 255, 10, 0)
+    assert g.checksum() != 0
+    g.snapshot_load(7)
+    _assert_same(g, (ln, mat, zp), "snapshot")
+    o = OracleGrid(case["domain"]["LX"], case["domain"]["LY"], 2, 2)
+    o.upload(ln, mat, zp, lm)
+    assert g.checksum() == o.checksum()
+    for pos in (-1e9, -64.0, -0.99, 0.0, 1.0, 2.999, 63.0, 1e9):
+        for ax in (0, 1):
+            assert g.index_from_pos(ax, pos) == o.index_from_pos(ax, pos)
+    g.close()
