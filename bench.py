@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the column-grid hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload: the 20-step three-mask flow of configuration C4 (fem_amd/flows.py) on a 16384 x 16384
+column grid per GPU, resident in HBM.  One bench "step" is one process step of the flow applied
+to every column (vertical deposit, masked anisotropic etch, conformal deposit or isotropic
+etch); when the flow wraps, the grid is re-created (createNewGrid) inside the timed region, as
+the reference's runtime does at the start of a rebuild (template/script_runtime.js:219-222).
+With N > 1 every rank owns one 16384-row slab of a (16384*N) x 16384 domain (weak scaling) and
+the stencil steps exchange R boundary rows with the neighbouring ranks over RCCL.
+
+Prints ONE JSON line (rank 0): metric = column updates per second, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=16384, help="columns per side per GPU (default 16384)")
+    ap.add_argument("--flow", default="c4", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--cpu-n", type=int, default=2048, help="grid side of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    return ap.parse_args()
+
+
+def build_masks(fem, flows, grid, specs, names, nx, ny, i0, LX, LY, device):
+    """Device rasters for the masks a flow uses (periodic ones in closed form on the GPU)."""
+    import torch
+    out = {}
+    for name in names:
+        spec = specs[name]
+        if spec["kind"] == "shapes":
+            out[name] = grid.mask_from_shapes(fem.reduce_mask(spec["data"]))
+        else:
+            r = flows.raster_torch(spec, nx, ny, i0, device)
+            torch.cuda.current_stream().synchronize()
+            out[name] = grid.mask_from_device_raster(r.data_ptr(), r.numel())
+            grid.sync()
+            del r
+    return out
+
+
+def cpu_baseline(flows, flow, n):
+    """The CPU restatement (oracle/, one thread) on an n x n sample of the same flow."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import OracleGrid
+    import numpy as np
+    specs = flows.mask_specs(2.0 * n)
+    o = OracleGrid(2.0 * n, 2.0 * n, 2.0, 2.0)
+    masks = {}
+    for s in flow:
+        m = s["mask"]
+        if m and m not in masks:
+            sp = specs[m]
+            if sp["kind"] == "shapes":
+                import fem_amd
+                masks[m] = o.mask_raster(fem_amd.reduce_mask(sp["data"]))
+            else:
+                masks[m] = flows.raster_numpy(sp, n, n)
+    t0 = time.perf_counter()
+    for s in flow:
+        flows.apply_step(o, s, masks)
+    dt = time.perf_counter() - t0
+    return {"value": n * n * len(flow) / dt / 1e9, "unit": "Gcol/s", "cores": 1, "kind": "port",
+            "sample": f"{n}x{n} grid, the same {len(flow)}-step flow once, oracle/colgrid_oracle.c single thread, "
+                      f"masks pre-rasterised, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import fem_amd
+    from fem_amd import flows
+    from fem_amd.slabs import SlabGrid
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    nxl = ny = args.n
+    nxg = nxl * world
+    LX, LY = 2.0 * nxg, 2.0 * ny
+    flow = flows.FLOWS[args.flow]()
+    specs = flows.mask_specs(LX)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        grid = fem_amd.ColumnGrid(dx=2.0, dy=2.0, slab=(nxg, ny, rank * nxl, nxl))
+        grid.set_stream(stream.cuda_stream)
+        names = sorted({s["mask"] for s in flow if s["mask"]})
+        masks = build_masks(fem_amd, flows, grid, specs, names, nxl, ny, rank * nxl, LX, LY, device)
+        slab = SlabGrid(grid, rank, world, device=device, dx=2.0, dy=2.0, ny=ny)
+
+        def run(nsteps, start=0):
+            k = start
+            for _ in range(nsteps):
+                if k % len(flow) == 0:
+                    slab.createNewGrid()
+                flows.apply_step(slab, flow[k % len(flow)], masks)
+                k += 1
+            return k
+
+        # ---- pass 0 (untimed): per-step column counts for the algorithmic-byte model
+        grid.stats_enable(True)
+        step_bytes = []
+        slab.createNewGrid()
+        for s in flow:
+            flows.apply_step(slab, s, masks)
+            step_bytes.append(flows.algorithmic_bytes(s["kind"], grid.stats()))
+        grid.stats_enable(False)
+        check = slab.checksum()
+
+        # ---- warmup
+        k = run(args.warmup, 0)
+        grid.sync()
+
+        # ---- timed region
+        grid.profile(True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps, k)
+        grid.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        prof = grid.profile(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # algorithmic bytes of the timed steps, per kernel kind (the kernel that applies the step)
+        def kind_of(s):
+            t = max(0.0, s["t"]); S = 0.0 if s["kind"] == "SUBSTR" else max(0.0, min(1.0, s["S"]))
+            stencil = t * S >= 2.0
+            if s["kind"] in ("SUBSTR", "DEPO"):
+                return "k_stencil_apply<deposit>" if stencil else "k_depo_vertical"
+            return "k_stencil_apply<etch>" if stencil else "k_etch_vertical"
+        kbytes = {}
+        for q in range(args.steps):
+            idx = (k + q) % len(flow)
+            kd = kind_of(flow[idx])
+            kbytes[kd] = kbytes.get(kd, 0) + step_bytes[idx]
+        kernels = {}
+        for name, (ms, cnt) in prof.items():
+            kernels[name] = {"ms_total": round(ms, 4), "launches": cnt, "ms_avg": round(ms / cnt, 4)}
+            if name in kbytes and ms > 0:
+                kernels[name]["algorithmic_GB"] = round(kbytes[name] / 1e9, 3)
+                kernels[name]["GBps"] = round(kbytes[name] / 1e9 / (ms / 1e3), 1)
+        cand = {n_: v for n_, v in kernels.items() if "GBps" in v}
+        dom = max(cand, key=lambda n_: cand[n_]["ms_total"]) if cand else None
+        roofline = None
+        if dom:
+            achieved = cand[dom]["GBps"]
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(achieved / 8000.0, 4), "traffic": None,
+                        "launches": cand[dom]["launches"], "ms_avg": cand[dom]["ms_avg"],
+                        "algorithmic_bytes_per_launch": int(kbytes[dom] / max(1, cand[dom]["launches"]))}
+        total_alg = sum(step_bytes[(k + q) % len(flow)] for q in range(args.steps))
+        cols = nxl * ny * world * args.steps
+        out = {
+            "metric": "column-updates/sec per process step", "value": round(cols / dt / 1e9, 4), "unit": "Gcol/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16 heights, f64/f32 arithmetic",
+            "data": "synthetic",
+            "config": {"workload": f"{args.flow.upper()} flow ({len(flow)} process steps, 3 masks) on a {nxl}x{ny} column grid per GPU",
+                       "grid": [nxg, ny], "lmax": grid.Lmax, "parallelism": f"slab{world}"},
+            "whole_flow_algorithmic_GBps": round(total_alg * world / 1e9 / dt, 1),
+            "checksum": "%016x" % check,
+            "roofline": roofline, "kernels": kernels,
+        }
+        if not args.no_cpu and world >= 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(flows, flow, args.cpu_n)
+            except Exception as e:  # the baseline is a reported extra, never the measured path
+                out["cpu_baseline"] = {"value": None, "unit": "Gcol/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    grid.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

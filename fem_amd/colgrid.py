@@ -19,6 +19,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcolgrid.so")
 
 CG_MASK_NONE = -1
 CG_NSTAT = 8
+CG_NKIND = 12
+KERNEL_KINDS = ["k_depo_vertical", "k_etch_vertical", "k_snapshot_tops", "k_halo_pack/unpack",
+                "k_stencil_apply<deposit>", "k_stencil_apply<etch>", "k_mask_shapes", "clear(memset)",
+                "k_max_top", "other", "-", "-"]
 STENCIL_DEPOSIT, STENCIL_ETCH = 0, 1
 SHAPE_RECT, SHAPE_CIRCLE, SHAPE_ELLIPSE, SHAPE_POLYGON, SHAPE_NEVER = range(5)
 
@@ -71,6 +75,8 @@ ABI = {
     "cg_stencil_begin": (_i, [_vp, _i, _i, _i, _d, _d, _i, _i, C.POINTER(_i)]),
     "cg_halo_buffers": (_i, [_vp, _pp, _pp, _pp, _pp, C.POINTER(_sz)]),
     "cg_stencil_finish": (_i, [_vp]),
+    "cg_set_halo_buffers": (_i, [_vp, _vp, _vp, _vp, _vp, _sz]),
+    "cg_profile": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_uint64)]),
     "cg_download": (_i, [_vp, _vp, _vp, _vp]),
     "cg_upload": (_i, [_vp, _vp, _vp, _vp, _i]),
     "cg_snapshot_save": (_i, [_vp, _i]),
@@ -89,6 +95,29 @@ ABI = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.
+
+    PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 and opens them by path.  If
+    libcolgrid pulled in the system runtime first, a later `import torch` would bring a second
+    runtime into the process and whichever initialises second sees no GPU.  So when torch is
+    installed its runtime is loaded first (without importing torch); libcolgrid's NEEDED entry
+    then binds to it by soname.  Processes without torch (e.g. the Node addon) use /opt/rocm.
+    """
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        p = os.path.join(libdir, name)
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def load_library(path=None):
     """Load libcolgrid.so and bind every ABI symbol.  Raises if the library or a symbol is missing."""
     global _lib
@@ -97,6 +126,7 @@ def load_library(path=None):
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise ColGridError(-1, f"{p} not found: build it with `make -C fem_amd/csrc` (hipcc, gfx950)")
+    _preload_torch_hip_runtime()
     lib = C.CDLL(p)
     for name, (res, args) in ABI.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -319,6 +349,15 @@ class ColumnGrid:
 
     def stencil_finish(self):
         self._chk(self.lib.cg_stencil_finish(self.h))
+
+    def set_halo_buffers(self, send_lower, send_upper, recv_lower, recv_upper, bytes_each):
+        self._chk(self.lib.cg_set_halo_buffers(self.h, send_lower, send_upper, recv_lower, recv_upper, bytes_each))
+
+    def profile(self, enable=True):
+        """-> {kernel kind: (ms, launches)} accumulated since the previous call; sets the enabled state."""
+        ms = (C.c_double * CG_NKIND)(); cnt = (C.c_uint64 * CG_NKIND)()
+        self._chk(self.lib.cg_profile(self.h, 1 if enable else 0, ms, cnt))
+        return {KERNEL_KINDS[k]: (ms[k], int(cnt[k])) for k in range(CG_NKIND) if cnt[k]}
 
     # ---- data exchange
     def download(self):

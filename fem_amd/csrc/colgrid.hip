@@ -74,6 +74,14 @@ struct cg_grid {
     // slice staging
     uint8_t* sl_mat = nullptr; uint16_t* sl_zp = nullptr; uint8_t* sl_len = nullptr; size_t sl_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // per-kernel timing (cg_profile): event pairs recorded around launches, resolved on read
+    bool prof_on = false;
+    struct ProfRec { int kind; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[CG_NKIND] = {0}; uint64_t prof_cnt[CG_NKIND] = {0};
+    // caller-owned halo buffers (cg_set_halo_buffers)
+    bool halo_external = false;
     std::string err;
 };
 
@@ -85,6 +93,21 @@ int fail(cg_grid* g, int code, const char* fmt, ...) {
     if (g) g->err = buf; else t_create_error = buf;
     return code;
 }
+
+hipEvent_t prof_event(cg_grid* g) {
+    if (!g->prof_pool.empty()) { hipEvent_t e = g->prof_pool.back(); g->prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+// RAII bracket: records an event pair around the launches made while it is alive
+struct ProfScope {
+    cg_grid* g; int kind; hipEvent_t a = nullptr;
+    ProfScope(cg_grid* g_, int kind_) : g(g_), kind(kind_) {
+        if (g->prof_on) { a = prof_event(g); if (a) (void)hipEventRecord(a, g->stream); }
+    }
+    ~ProfScope() {
+        if (a) { hipEvent_t b = prof_event(g); if (b) { (void)hipEventRecord(b, g->stream); g->prof_recs.push_back({kind, a, b}); } }
+    }
+};
 
 #define HIPCHK(g, call)                                                                       \
     do {                                                                                      \
@@ -144,9 +167,15 @@ int alloc_planes(cg_grid* g, int lmax) {
     return CG_OK;
 }
 
-int zero_planes(cg_grid* g) {
-    size_t S = g->N * (size_t)g->lmax;
+// Empty every column.  Slots at or above a column's length are zero by invariant (removed
+// layers are cleared), so only the planes below the host-tracked bound of max(len) can hold
+// anything; `all` forces every plane (fresh allocations).
+int zero_planes(cg_grid* g, bool all = true) {
+    ProfScope ps(g, CG_K_CLEAR);
+    const int planes = all ? g->lmax : std::min(g->lmax, std::max(0, g->len_bound));
+    size_t S = g->N * (size_t)planes;
     HIPCHK(g, hipMemsetAsync(g->len, 0, g->N, g->stream));
+    if (S == 0) { g->len_bound = 0; g->has_gaps = false; return CG_OK; }
     HIPCHK(g, hipMemsetAsync(g->mat, 0, S, g->stream));
     HIPCHK(g, hipMemsetAsync(g->z0, 0, 2 * S, g->stream));
     HIPCHK(g, hipMemsetAsync(g->z1, 0, 2 * S, g->stream));
@@ -181,7 +210,8 @@ int read_flags(cg_grid* g, int out[4]) {
 
 int refresh_len_bound(cg_grid* g, unsigned* topq_out) {
     HIPCHK(g, hipMemsetAsync(g->d_red, 0, 2 * sizeof(unsigned), g->stream));
-    hipLaunchKernelGGL(k_max_top, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_red);
+    { ProfScope ps(g, CG_K_REDUCE);
+      hipLaunchKernelGGL(k_max_top, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_red); }
     unsigned r[2];
     HIPCHK(g, hipMemcpyAsync(r, g->d_red, sizeof r, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(g, hipStreamSynchronize(g->stream));
@@ -267,6 +297,8 @@ int ensure_stencil_scratch(cg_grid* g, int R, bool etch) {
     }
     (void)etch;
     size_t hneed = (size_t)R * g->ny * 3;
+    if (hneed > g->halo_cap && g->halo_external)
+        return fail(g, CG_ERR_ARG, "caller's halo buffers hold %zu bytes each, this step needs %zu", g->halo_cap, hneed);
     if (hneed > g->halo_cap) {
         for (auto& h : g->halo) { if (h) (void)hipFree(h); h = nullptr; }
         g->halo_cap = 0;
@@ -282,6 +314,7 @@ int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
     if (may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; may_overflow = g->len_bound >= g->lmax; }
     if (may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
     const dim3 grid(blocks_for(g->N)), blk(256);
+    ProfScope ps(g, CG_K_DEPO_VERTICAL);
     if (g->stats_on) hipLaunchKernelGGL(k_depo_vertical<true>, grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
     else hipLaunchKernelGGL(k_depo_vertical<false>, grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
     HIPCHK(g, hipGetLastError());
@@ -303,6 +336,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
     const int tiles = ((g->nx + TI - 1) / TI) * ((g->ny + TJ - 1) / TJ);
     const size_t lds = stencil_lds_bytes(R);
     const dim3 grid(tiles), blk(256);
+    ProfScope ps(g, etch ? CG_K_STENCIL_ETCH : CG_K_STENCIL_DEPOSIT);
 #define LAUNCH(E, S)                                                                                           \
     do {                                                                                                       \
         if (lds > 48 * 1024)                                                                                   \
@@ -380,7 +414,9 @@ int cg_destroy(cg_grid* g) {
     for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.mat); (void)hipFree(s.second.z0); (void)hipFree(s.second.z1); }
     if (g->topq) (void)hipFree(g->topq);
     if (g->eflag) (void)hipFree(g->eflag);
-    for (auto h : g->halo) if (h) (void)hipFree(h);
+    if (!g->halo_external) for (auto h : g->halo) if (h) (void)hipFree(h);
+    for (auto& r : g->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : g->prof_pool) (void)hipEventDestroy(e);
     if (g->d_flags) (void)hipFree(g->d_flags);
     if (g->d_red) (void)hipFree(g->d_red);
     if (g->d_sum) (void)hipFree(g->d_sum);
@@ -403,11 +439,12 @@ int cg_reset(cg_grid* g, int lmax_init) {
     if (lmax != g->lmax) {
         HIPCHK(g, hipStreamSynchronize(g->stream));
         int rc = alloc_planes(g, lmax); if (rc) return rc;
+        return zero_planes(g, true);
     }
-    return zero_planes(g);
+    return zero_planes(g, g->len_bound > g->lmax);
 }
 
-int cg_clear(cg_grid* g) { NEED(g); g->pend.active = false; return zero_planes(g); }
+int cg_clear(cg_grid* g) { NEED(g); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
 
 int cg_get_info(const cg_grid* g, cg_info* o) {
     if (!g || !o) return CG_ERR_ARG;
@@ -469,6 +506,7 @@ int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const d
     HIPCHK(g, hipMalloc(&d_pts, std::max(1, npts) * 2 * sizeof(double)));
     if (nshapes) HIPCHK(g, hipMemcpyAsync(d_sh, shapes, nshapes * sizeof(Shape), hipMemcpyHostToDevice, g->stream));
     if (npts) HIPCHK(g, hipMemcpyAsync(d_pts, pts, (size_t)npts * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    ProfScope ps(g, CG_K_MASK);
     hipLaunchKernelGGL(k_mask_shapes, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, g->nx, g->ny, g->i0, g->dx, g->dy, d_sh, nshapes,
                        d_pts, buf);
     HIPCHK(g, hipGetLastError());
@@ -514,6 +552,7 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     if (latRange < std::min(g->dx, g->dy)) {                              // cg1:445, 609
         if (kind == CG_STENCIL_DEPOSIT) return run_depo_vertical(g, mask, mat, t);
         const dim3 grid(blocks_for(g->N)), blk(256);
+        ProfScope ps(g, CG_K_ETCH_VERTICAL);
         if (g->stats_on) hipLaunchKernelGGL(k_etch_vertical<true>, grid, blk, 0, g->stream, view(g), mask, mat, t, g->d_stats);
         else hipLaunchKernelGGL(k_etch_vertical<false>, grid, blk, 0, g->stream, view(g), mask, mat, t, g->d_stats);
         HIPCHK(g, hipGetLastError());
@@ -530,14 +569,18 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     int rc = ensure_stencil_scratch(g, R, kind == CG_STENCIL_ETCH); if (rc) return rc;
     rc = upload_taps(g, K, R); if (rc) return rc;
     const dim3 grid(blocks_for(g->N)), blk(256);
-    if (kind == CG_STENCIL_ETCH) {
-        HIPCHK(g, hipMemsetAsync(g->d_flags + 1, 0, sizeof(int), g->stream));
-        hipLaunchKernelGGL(k_snapshot_tops<true>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag, g->d_flags);
-    } else {
-        hipLaunchKernelGGL(k_snapshot_tops<false>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag, g->d_flags);
+    {
+        ProfScope ps(g, CG_K_SNAPSHOT);
+        if (kind == CG_STENCIL_ETCH) {
+            HIPCHK(g, hipMemsetAsync(g->d_flags + 1, 0, sizeof(int), g->stream));
+            hipLaunchKernelGGL(k_snapshot_tops<true>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag, g->d_flags);
+        } else {
+            hipLaunchKernelGGL(k_snapshot_tops<false>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag, g->d_flags);
+        }
     }
     HIPCHK(g, hipGetLastError());
     if (has_lower || has_upper) {
+        ProfScope ps(g, CG_K_HALO);
         hipLaunchKernelGGL(k_halo_pack, dim3(blocks_for((size_t)R * g->ny)), blk, 0, g->stream, g->topq,
                            kind == CG_STENCIL_ETCH ? g->eflag : (const uint8_t*)nullptr, g->nx, g->ny, R, g->halo[0], g->halo[1]);
         HIPCHK(g, hipGetLastError());
@@ -560,6 +603,22 @@ int cg_halo_buffers(cg_grid* g, void** send_lower, void** send_upper, void** rec
     return CG_OK;
 }
 
+int cg_set_halo_buffers(cg_grid* g, void* send_lower, void* send_upper, void* recv_lower, void* recv_upper, size_t bytes_each) {
+    NEED(g);
+    if (g->pend.active) return fail(g, CG_ERR_STATE, "a stencil step is open");
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    if (!g->halo_external) for (auto& h : g->halo) { if (h) (void)hipFree(h); h = nullptr; }
+    g->halo_cap = 0; g->halo_external = false;
+    for (auto& h : g->halo) h = nullptr;
+    if (!send_lower && !send_upper && !recv_lower && !recv_upper) return CG_OK;      // back to library-owned
+    if (!send_lower || !send_upper || !recv_lower || !recv_upper || bytes_each == 0)
+        return fail(g, CG_ERR_ARG, "need four buffers and a size");
+    g->halo[0] = (uint8_t*)send_lower; g->halo[1] = (uint8_t*)send_upper;
+    g->halo[2] = (uint8_t*)recv_lower; g->halo[3] = (uint8_t*)recv_upper;
+    g->halo_cap = bytes_each; g->halo_external = true;
+    return CG_OK;
+}
+
 int cg_stencil_finish(cg_grid* g) {
     NEED(g);
     if (!g->pend.active) return fail(g, CG_ERR_STATE, "no stencil step is open");
@@ -568,9 +627,10 @@ int cg_stencil_finish(cg_grid* g) {
     bool ok; const uint8_t* mask = mask_ptr(g, p.mask_id, &ok);
     if (!ok) return fail(g, CG_ERR_ARG, "mask %d vanished during the step", p.mask_id);
     const bool etch = p.kind == CG_STENCIL_ETCH;
+    { ProfScope ps(g, CG_K_HALO);
     hipLaunchKernelGGL(k_halo_unpack, dim3(blocks_for((size_t)p.R * g->ny)), dim3(256), 0, g->stream, g->topq,
                        etch ? g->eflag : (uint8_t*)nullptr, g->nx, g->ny, p.R, p.has_lower ? g->halo[2] : (const uint8_t*)nullptr,
-                       p.has_upper ? g->halo[3] : (const uint8_t*)nullptr);
+                       p.has_upper ? g->halo[3] : (const uint8_t*)nullptr); }
     HIPCHK(g, hipGetLastError());
     if (etch) return launch_stencil(g, true, mask, p.mat, p.t_eff, p.R, p.K, -1);
 
@@ -803,6 +863,24 @@ int cg_step_stats(cg_grid* g, int enable, uint64_t stats[CG_NSTAT]) {
         stats[0] = g->N;
     }
     g->stats_on = enable != 0;
+    return CG_OK;
+}
+
+int cg_profile(cg_grid* g, int enable, double ms[CG_NKIND], uint64_t count[CG_NKIND]) {
+    NEED(g);
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    for (auto& r : g->prof_recs) {
+        float v = 0;
+        if (hipEventElapsedTime(&v, r.a, r.b) == hipSuccess && r.kind >= 0 && r.kind < CG_NKIND) { g->prof_ms[r.kind] += v; g->prof_cnt[r.kind] += 1; }
+        g->prof_pool.push_back(r.a); g->prof_pool.push_back(r.b);
+    }
+    g->prof_recs.clear();
+    for (int k = 0; k < CG_NKIND; k++) {
+        if (ms) ms[k] = g->prof_ms[k];
+        if (count) count[k] = g->prof_cnt[k];
+        g->prof_ms[k] = 0; g->prof_cnt[k] = 0;
+    }
+    g->prof_on = enable != 0;
     return CG_OK;
 }
 

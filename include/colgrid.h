@@ -182,6 +182,11 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
 int cg_halo_buffers(cg_grid* g, void** send_lower, void** send_upper,
                     void** recv_lower, void** recv_upper, size_t* bytes_each);
 int cg_stencil_finish(cg_grid* g);
+/* Let the caller own the four halo buffers (device memory, bytes_each >= R*ny*3 for every
+ * step to come), e.g. tensors of the framework that does the communication.  Four NULLs
+ * return to library-owned buffers. */
+int cg_set_halo_buffers(cg_grid* g, void* send_lower, void* send_upper,
+                        void* recv_lower, void* recv_upper, size_t bytes_each);
 
 /* ---- data exchange with the host (the `cols` contract, script_gridrenderer.js:216-263) */
 
@@ -225,6 +230,23 @@ int cg_checksum(cg_grid* g, uint64_t* sum);
  * appended, [4] columns etched, [5] whole layers removed, [6] layers scanned for the floor. */
 #define CG_NSTAT 8
 int cg_step_stats(cg_grid* g, int enable, uint64_t stats[CG_NSTAT]);
+
+/* Per-kernel timing.  While enabled, every kernel launch of this handle is bracketed by a
+ * pair of HIP events on the handle's stream (no host synchronisation at launch time).
+ * A call synchronises the stream, returns the milliseconds and launch counts accumulated
+ * per kernel kind since the previous call, clears them, and sets the enabled state. */
+#define CG_K_DEPO_VERTICAL   0   /* k_depo_vertical                                            */
+#define CG_K_ETCH_VERTICAL   1   /* k_etch_vertical                                            */
+#define CG_K_SNAPSHOT        2   /* k_snapshot_tops                                            */
+#define CG_K_HALO            3   /* k_halo_pack / k_halo_unpack                                */
+#define CG_K_STENCIL_DEPOSIT 4   /* k_stencil_apply<deposit>                                   */
+#define CG_K_STENCIL_ETCH    5   /* k_stencil_apply<etch>                                      */
+#define CG_K_MASK            6   /* k_mask_shapes                                              */
+#define CG_K_CLEAR           7   /* memsets of cg_reset / cg_clear                             */
+#define CG_K_REDUCE          8   /* k_max_top                                                  */
+#define CG_K_OTHER           9
+#define CG_NKIND 12
+int cg_profile(cg_grid* g, int enable, double ms[CG_NKIND], uint64_t count[CG_NKIND]);
 
 /* HIP-event timing on the handle's stream: cg_timer_start records an event, cg_timer_stop
  * records a second one, waits for it and returns the elapsed milliseconds in between. */
