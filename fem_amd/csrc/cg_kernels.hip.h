@@ -1,15 +1,23 @@
 // Device code of libcolgrid: the per-column process kernels for gfx950 (MI355X).
 //
 // Data layout (all in HBM, owned by the handle):
-//   len[c]        u8   layers in column c                      c = i*NY + j, j fastest
-//   mat[k*N + c]  u8   material of layer k                     "plane-major": the 64 lanes of a
-//   z0 [k*N + c]  u16  quantised bottom of layer k             wavefront that touch layer k of 64
-//   z1 [k*N + c]  u16  quantised top of layer k                neighbouring columns read one line
+//   len[c]          u8    intervals in column c                   c = i*NY + j, j fastest
+//   rec[k*N + c]    u32   interval k of column c ("plane-major")  z1q | mat << 16 | flags << 24
+//
+// A column is a stack of contiguous intervals; interval k spans from the top of interval k-1
+// (0 for k = 0) to its own z1, so the bottom height is never stored.  That is exactly what the
+// reference's columns look like as long as they have no vertical gaps (every append starts at
+// the old top, script_columngrid.js:419-423).  A gap -- left behind when strip_connected
+// removes a buried layer -- is kept as an interval of its own with the HOLE flag; holes are not
+// layers of the reference (they do not count in its len, cg_download skips them) and the top
+// interval is never a hole.  One 4-byte record per (plane, column) means one memory stream per
+// plane and 16 bytes per 4-column group: HBM is only reached with >= 4 bytes per lane and
+// access (measured on MI355X: 1 B/lane copies at 1.8 TB/s, 2 B/lane 3.0, 4 B/lane 5.4).
 //
 // Arithmetic follows the reference's JavaScript: heights are u16 steps of zscale nm,
 // de-quantised as (double)q*zscale, re-quantised as Math.round(z/zscale) (halves toward
-// +infinity) and stored modulo 2^16 (template/script_columngrid.js:117-122, 85).  This file
-// must be compiled with -ffp-contract=off: the reference rounds after every operation.
+// +infinity) and stored modulo 2^16 (script_columngrid.js:117-122, 85).  This file must be
+// compiled with -ffp-contract=off: the reference rounds after every operation.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,15 +28,21 @@ namespace cgk {
 
 struct GridView {
     uint8_t*  len;
-    uint8_t*  mat;
-    uint16_t* z0;
-    uint16_t* z1;
+    uint32_t* rec;
     size_t    N;        // columns of this handle
     int       nx, ny;
     int       lmax;     // planes provisioned
     int       i0;       // global row of local row 0
     double    zs;       // nm per step
+    double    inv_zs;   // 1/zs, rounded once on the host
 };
+
+constexpr uint32_t REC_HOLE = 1u << 24;
+__device__ __forceinline__ uint32_t rec_make(uint32_t z1q, int mat) { return (z1q & 0xffffu) | ((uint32_t)(mat & 255) << 16); }
+__device__ __forceinline__ uint32_t rec_z1(uint32_t r) { return r & 0xffffu; }
+__device__ __forceinline__ int rec_mat(uint32_t r) { return (int)((r >> 16) & 255u); }
+__device__ __forceinline__ bool rec_hole(uint32_t r) { return (r & REC_HOLE) != 0; }
+__device__ __forceinline__ uint32_t rec_with_z1(uint32_t r, uint32_t z1q) { return (r & 0xffff0000u) | (z1q & 0xffffu); }
 
 // statistics slots (cg_step_stats)
 enum { ST_VISITED = 0, ST_OPEN = 1, ST_EXTEND = 2, ST_APPEND = 3, ST_ETCHED = 4, ST_REMOVED = 5, ST_FLOOR = 6, ST_N = 8 };
@@ -43,10 +57,28 @@ __device__ __forceinline__ uint16_t to_u16(double v) {
     if (!(fabs(v) < 9.0e18)) return 0;          // NaN / inf / absurd
     return (uint16_t)(long long)v;
 }
-__device__ __forceinline__ uint16_t quantz(double z, double zs) { return to_u16(js_round(z / zs)); }
+// Math.round(z / zs) stored into a Uint16Array element -- the literal form: IEEE division,
+// round half toward +infinity, conversion through 64-bit integers.  About 100 double-rate
+// instructions; kept for the rare inputs the shortcut below cannot decide.
+__device__ __noinline__ uint16_t quantz_exact(double z, double zs) { return to_u16(js_round(z / zs)); }
+
+// The same value without the division.  y = z * (1/zs) differs from the correctly rounded
+// quotient by at most 3.3e-16 * |y| (two roundings), i.e. < 4e-10 for |y| < 1e6.  Math.round
+// of the quotient is the integer nearest to it unless the quotient sits within that distance
+// of a half-integer; so when y is farther than 1e-8 from every half-integer, rint(y) is the
+// answer, and otherwise (t = 7.25 nm at 0.1 nm steps, say) the literal form decides.
+__device__ __forceinline__ uint16_t quantz(double z, double zs, double inv_zs) {
+    const double y = z * inv_zs;
+    const double r = rint(y);
+    if (fabs(y - r) < 0.49999999 && fabs(y) < 1.0e6) return (uint16_t)(int)r;
+    return quantz_exact(z, zs);
+}
+// Note: Math.round((q*zs)/zs) == q for every q < 2^16 (the two roundings move the quotient by
+// < 2e-11), so the bottom of an appended layer, quantize(topZ) at script_columngrid.js:422, is
+// the old top's z1q itself -- which is why the bottom need not be stored.
 
 // ------------------------------------------------------------------------------------------
-// per-column update primitives
+// per-column update primitives (scalar forms; the vector forms below do the same per lane)
 // ------------------------------------------------------------------------------------------
 
 // _depoAtTop_ (script_columngrid.js:397-426) for one column.  `l` is the column's current
@@ -54,23 +86,14 @@ __device__ __forceinline__ uint16_t quantz(double z, double zs) { return to_u16(
 // but no plane left (column untouched; the host grows the planes and re-runs those columns).
 __device__ __forceinline__ int depo_at_top(const GridView& g, size_t c, int l, int matId, double dz) {
     if (!(dz > 0)) return 0;
-    double topZ = 0; int topMat = 0;
+    uint32_t r = 0;
     size_t top = 0;
-    if (l > 0) {
-        top = (size_t)(l - 1) * g.N + c;
-        topZ = (double)g.z1[top] * g.zs;
-        topMat = g.mat[top];
-    }
-    double newTop = topZ + dz;
-    if (l > 0 && topMat == matId) {
-        g.z1[top] = quantz(newTop, g.zs);
-        return 1;
-    }
+    if (l > 0) { top = (size_t)(l - 1) * g.N + c; r = g.rec[top]; }
+    const uint32_t topq = rec_z1(r);
+    const uint16_t q = quantz((double)topq * g.zs + dz, g.zs, g.inv_zs);
+    if (l > 0 && rec_mat(r) == matId) { g.rec[top] = rec_with_z1(r, q); return 1; }
     if (l >= g.lmax) return 3;
-    size_t b = (size_t)l * g.N + c;
-    g.mat[b] = (uint8_t)matId;
-    g.z0[b] = quantz(topZ, g.zs);
-    g.z1[b] = quantz(newTop, g.zs);
+    g.rec[(size_t)l * g.N + c] = rec_make(q, matId);
     g.len[c] = (uint8_t)(l + 1);
     return 2;
 }
@@ -82,25 +105,51 @@ __device__ __forceinline__ int apply_etch_at(const GridView& g, size_t c, int l,
     double remaining = dz;
     int removed = 0, touched = 0;
     const int l0 = l;
+    uint32_t r = l > 0 ? g.rec[(size_t)(l - 1) * g.N + c] : 0;
     while (remaining > CG_EPS && l > 0) {
-        size_t b = (size_t)(l - 1) * g.N + c;
-        int curMat = g.mat[b];
-        if (!isAll && curMat != matId) break;
-        double z0 = (double)g.z0[b] * g.zs, z1 = (double)g.z1[b] * g.zs;
-        double thick = z1 - z0;
+        if (!isAll && rec_mat(r) != matId) break;
+        const uint32_t below = l > 1 ? g.rec[(size_t)(l - 2) * g.N + c] : 0;
+        const double z1 = (double)rec_z1(r) * g.zs, z0 = (double)rec_z1(below) * g.zs;
+        const double thick = z1 - z0;
         touched = 0x10000;
         if (remaining < thick - CG_EPS) {
-            g.z1[b] = quantz(z1 - remaining, g.zs);
+            g.rec[(size_t)(l - 1) * g.N + c] = rec_with_z1(r, quantz(z1 - remaining, g.zs, g.inv_zs));
             remaining = 0;
         } else {
             remaining -= thick;
-            l -= 1;
-            g.mat[b] = 0; g.z0[b] = 0; g.z1[b] = 0;      // removed slots are cleared (cg1:584-586)
-            removed++;
+            g.rec[(size_t)(l - 1) * g.N + c] = 0;          // removed slots are cleared (cg1:584-586)
+            l -= 1; removed++;
+            r = below;
+            if (l > 0 && rec_hole(r)) {                    // a gap under the removed layer goes with it
+                g.rec[(size_t)(l - 1) * g.N + c] = 0;
+                l -= 1;
+                r = l > 0 ? g.rec[(size_t)(l - 1) * g.N + c] : 0;
+            }
         }
     }
     if (l != l0) g.len[c] = (uint8_t)l;
     return touched | removed;
+}
+
+// bottom of the top run of matId (script_columngrid.js:646-660); the top layer is known to be
+// matId.  Gaps do not interrupt the run (the reference only compares materials).
+__device__ __forceinline__ double floor_of_top_run(const GridView& g, size_t c, int l, int matId, unsigned& scanned) {
+    int s = l - 1;                 // interval whose bottom is the current floor
+    scanned++;
+    while (s > 0) {
+        uint32_t b = g.rec[(size_t)(s - 1) * g.N + c];
+        int nb = s - 1;
+        if (rec_hole(b)) {         // look through the gap at the layer under it
+            if (nb == 0) break;
+            uint32_t b2 = g.rec[(size_t)(nb - 1) * g.N + c];
+            if (rec_mat(b2) != matId) break;
+            s = nb - 1; scanned++;
+            continue;
+        }
+        if (rec_mat(b) != matId) break;
+        s = nb; scanned++;
+    }
+    return s > 0 ? (double)rec_z1(g.rec[(size_t)(s - 1) * g.N + c]) * g.zs : 0.0;
 }
 
 // block-wide accumulation of statistics into global counters
@@ -120,43 +169,227 @@ __device__ __forceinline__ void stats_commit(unsigned long long* gstats, const u
 }
 
 // ------------------------------------------------------------------------------------------
-// vertical steps (fast paths of deposit_general / etch_general, cg1:445-454 and 609-618)
+// vertical steps, one column per thread (any N; also the re-run after the planes were grown)
 // ------------------------------------------------------------------------------------------
-
-// only_len < 0: normal run.  only_len >= 0: second pass after the planes were grown -- touch
-// only the columns that could not append in the first pass (len == only_len, top differs).
-template <bool STATS>
-__global__ __launch_bounds__(256) void k_depo_vertical(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
-                                                       int only_len, int* __restrict__ flags, unsigned long long* gstats) {
-    unsigned loc[3] = {0, 0, 0};
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
-        if (mask && !mask[c]) continue;
-        int l = g.len[c];
-        if (only_len >= 0) {
-            if (l != only_len) continue;
-            if (l > 0 && g.mat[(size_t)(l - 1) * g.N + c] == matId) continue;
-        }
-        int r = depo_at_top(g, c, l, matId, t);
-        if (r == 3) flags[0] = 1;
-        if (STATS) { loc[0]++; loc[1] += (r == 1); loc[2] += (r == 2); }
-    }
-    if (STATS) { const int slot[3] = {ST_OPEN, ST_EXTEND, ST_APPEND}; stats_commit<3>(gstats, loc, slot); }
-}
-
-template <bool STATS>
-__global__ __launch_bounds__(256) void k_etch_vertical(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
-                                                       unsigned long long* gstats) {
+// only_len < 0: normal run.  only_len >= 0 (deposit): touch only the columns that could not
+// append in the first pass (len == only_len and the top is another material).
+template <bool ETCH, bool STATS>
+__global__ __launch_bounds__(256) void k_vertical_1(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
+                                                    int only_len, int* __restrict__ flags, unsigned long long* gstats) {
     unsigned loc[3] = {0, 0, 0};
     const bool isAll = (matId == 255);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         if (mask && !mask[c]) continue;
-        int l = g.len[c];
-        int r = apply_etch_at(g, c, l, matId, t, isAll);
-        if (STATS) { loc[0]++; loc[1] += (r >> 16); loc[2] += (r & 0xffff); }
+        const int l = g.len[c];
+        if (ETCH) {
+            const int r = apply_etch_at(g, c, l, matId, t, isAll);
+            if (STATS) { loc[0]++; loc[1] += (r >> 16); loc[2] += (r & 0xffff); }
+        } else {
+            if (only_len >= 0) {
+                if (l != only_len) continue;
+                if (l > 0 && rec_mat(g.rec[(size_t)(l - 1) * g.N + c]) == matId) continue;
+            }
+            const int r = depo_at_top(g, c, l, matId, t);
+            if (r == 3) flags[0] = 1;
+            if (STATS) { loc[0]++; loc[1] += (r == 1); loc[2] += (r == 2); }
+        }
     }
-    if (STATS) { const int slot[3] = {ST_OPEN, ST_ETCHED, ST_REMOVED}; stats_commit<3>(gstats, loc, slot); }
+    if (STATS) {
+        if (ETCH) { const int slot[3] = {ST_OPEN, ST_ETCHED, ST_REMOVED}; stats_commit<3>(gstats, loc, slot); }
+        else { const int slot[3] = {ST_OPEN, ST_EXTEND, ST_APPEND}; stats_commit<3>(gstats, loc, slot); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 4 columns per thread ("groups")
+// ------------------------------------------------------------------------------------------
+// A thread owns 4 consecutive columns: len and mask move as one dword, a plane's records as
+// one 16-byte vector.  Neighbouring columns usually have the same number of layers, so their
+// tops share a plane.  Columns of a group with differing lengths are handled length by
+// length; every store is a whole vector in which the lanes of the other columns carry the
+// values just loaded (the thread owns all 4 columns, nobody else writes them).  N % 4 == 0.
+typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned as_u32(u8x4 v) { union { u8x4 a; unsigned b; } u; u.a = v; return u.b; }
+__device__ __forceinline__ u8x4 splat4(int x) { union { u8x4 a; unsigned b; } u; u.b = 0x01010101u * (unsigned)(x & 255); return u.a; }
+__device__ __forceinline__ u8x4 ld_u8x4(const uint8_t* p) { return *(const u8x4*)p; }
+__device__ __forceinline__ void st_u8x4(uint8_t* p, u8x4 v) { *(u8x4*)p = v; }
+__device__ __forceinline__ u32x4 ld_rec4(const uint32_t* p) { return *(const u32x4*)p; }
+__device__ __forceinline__ void st_rec4(uint32_t* p, u32x4 v) { *(u32x4*)p = v; }
+__device__ __forceinline__ unsigned open_bits(u8x4 mk) { return (mk[0] ? 1u : 0u) | (mk[1] ? 2u : 0u) | (mk[2] ? 4u : 0u) | (mk[3] ? 8u : 0u); }
+__device__ __forceinline__ int first_open_len(unsigned open, u8x4 ln) {
+    return (open & 1) ? ln[0] : (open & 2) ? ln[1] : (open & 4) ? ln[2] : ln[3];
+}
+
+// top plane of a group, loaded ahead of time for the length of its first open column
+struct Pre4 { int l; u32x4 top; };
+
+// _depoAtTop_ on the open columns of a group: column j grows by dz[j] (> 0).
+template <bool STATS>
+__device__ __forceinline__ void depo_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
+                                            const Pre4& pre, int* __restrict__ flags, unsigned& n_ext, unsigned& n_app) {
+    u8x4 nl = ln; bool len_dirty = false;
+    const int lj[4] = {ln[0], ln[1], ln[2], ln[3]};
+    const int lmax_all = max(max(lj[0], lj[1]), max(lj[2], lj[3]));
+    unsigned rem = open;
+    while (rem) {
+        const int l = first_open_len(rem, ln);
+        unsigned sel = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (((rem >> j) & 1) && lj[j] == l) sel |= 1u << j;
+        rem &= ~sel;
+        u32x4 tv = (u32x4)(0);
+        size_t top = 0;
+        if (l > 0) { top = (size_t)(l - 1) * g.N + c0; tv = (pre.l == l) ? pre.top : ld_rec4(g.rec + top); }
+        unsigned ext = 0;
+        uint32_t q[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!((sel >> j) & 1)) continue;
+            q[j] = quantz((double)rec_z1(tv[j]) * g.zs + dz[j], g.zs, g.inv_zs);
+            if (l > 0 && rec_mat(tv[j]) == matId) ext |= 1u << j;
+        }
+        const unsigned app = sel & ~ext;
+        if (ext) {
+            u32x4 nv = tv;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if ((ext >> j) & 1) nv[j] = rec_with_z1(tv[j], q[j]);
+            st_rec4(g.rec + top, nv);
+            if (STATS) n_ext += __popc(ext);
+        }
+        if (app) {
+            if (l >= g.lmax) flags[0] = 1;      // no plane left: the host grows the planes and re-runs these columns
+            else {
+                const size_t b = (size_t)l * g.N + c0;
+                u32x4 av = (u32x4)(0);
+                if (lmax_all > l) av = ld_rec4(g.rec + b);       // a taller neighbour lives in this plane
+#pragma unroll
+                for (int j = 0; j < 4; j++) if ((app >> j) & 1) { av[j] = rec_make(q[j], matId); nl[j] = (uint8_t)(l + 1); }
+                st_rec4(g.rec + b, av);
+                len_dirty = true;
+                if (STATS) n_app += __popc(app);
+            }
+        }
+    }
+    if (len_dirty) st_u8x4(g.len + c0, nl);
+}
+
+// _applyEtchAt on the open columns of a group: column j loses dz[j] (> 0) from the top.
+// Columns of equal length stay in lockstep: every pass takes exactly one layer off those that
+// keep going.  A column that uncovers a gap leaves the lockstep and finishes on its own.
+template <bool STATS>
+__device__ __forceinline__ void etch_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
+                                            bool isAll, const Pre4& pre, unsigned& n_touched, unsigned& n_removed) {
+    u8x4 nl = ln; bool len_dirty = false;
+    const int lj[4] = {ln[0], ln[1], ln[2], ln[3]};
+    unsigned rem = open, touched = 0, solo = 0;
+    double solo_r[4] = {0, 0, 0, 0};
+    bool first = true;
+    while (rem) {
+        const int l = first_open_len(rem, ln);
+        unsigned active = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (((rem >> j) & 1) && lj[j] == l) active |= 1u << j;
+        rem &= ~active;
+        double r[4] = {dz[0], dz[1], dz[2], dz[3]};
+        u32x4 tv = (u32x4)(0);
+        if (l > 0) tv = (first && pre.l == l) ? pre.top : ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0);
+        first = false;
+        for (int cur = l; active && cur > 0; cur--) {
+            // which active columns does this layer concern at all?
+            unsigned hit = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (((active >> j) & 1) && r[j] > CG_EPS && (isAll || rec_mat(tv[j]) == matId)) hit |= 1u << j;
+            if (!hit) break;
+            const u32x4 bv = cur > 1 ? ld_rec4(g.rec + (size_t)(cur - 2) * g.N + c0) : (u32x4)(0);
+            u32x4 nv = tv;
+            unsigned next = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!((hit >> j) & 1)) continue;
+                const double z1 = (double)rec_z1(tv[j]) * g.zs, z0 = (double)rec_z1(bv[j]) * g.zs, thick = z1 - z0;
+                touched |= 1u << j;
+                if (r[j] < thick - CG_EPS) { nv[j] = rec_with_z1(tv[j], quantz(z1 - r[j], g.zs, g.inv_zs)); r[j] = 0; }
+                else {
+                    r[j] -= thick; nv[j] = 0;                       // removed slots are cleared (cg1:584-586)
+                    nl[j] = (uint8_t)(cur - 1); len_dirty = true;
+                    if (STATS) n_removed++;
+                    if (cur > 1 && rec_hole(bv[j])) { solo |= 1u << j; solo_r[j] = r[j]; }   // gap uncovered
+                    else next |= 1u << j;
+                }
+            }
+            st_rec4(g.rec + (size_t)(cur - 1) * g.N + c0, nv);
+            active = next;
+            tv = bv;
+        }
+    }
+    if (len_dirty) st_u8x4(g.len + c0, nl);
+    if (solo) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!((solo >> j) & 1)) continue;
+            int l = nl[j];                                          // the hole is the top interval now
+            g.rec[(size_t)(l - 1) * g.N + c0 + j] = 0; l -= 1;
+            g.len[c0 + j] = (uint8_t)l;
+            const int rr = apply_etch_at(g, c0 + j, l, matId, solo_r[j], isAll);
+            if (STATS) n_removed += (rr & 0xffff);
+        }
+    }
+    if (STATS) n_touched += __popc(touched);
+}
+
+// Vertical deposit / etch (fast paths, cg1:445-454 and 609-618).  A thread owns U groups that
+// are 256 groups apart; the U len/mask words are loaded together, then the U top planes, and
+// only then anything is computed or stored: U dependent-load chains in flight per thread.
+template <bool ETCH, bool STATS, int U>
+__global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
+                                                     int* __restrict__ flags, unsigned long long* gstats) {
+    unsigned loc[3] = {0, 0, 0};
+    const bool isAll = (matId == 255);
+    const size_t ngroups = g.N >> 2;
+    const size_t tile_groups = (size_t)256 * U;
+    const size_t ntiles = (ngroups + tile_groups - 1) / tile_groups;
+    const double dz[4] = {t, t, t, t};
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t gbase = tile * tile_groups + threadIdx.x;
+        u8x4 ln[U]; unsigned open[U]; Pre4 pre[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t gi = gbase + (size_t)u * 256;
+            open[u] = 0; ln[u] = splat4(0);
+            if (gi < ngroups) {
+                const size_t c0 = gi << 2;
+                open[u] = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
+                ln[u] = ld_u8x4(g.len + c0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            pre[u].l = -1;
+            if (!open[u]) continue;
+            const int l = first_open_len(open[u], ln[u]);
+            if (l > 0) { pre[u].l = l; pre[u].top = ld_rec4(g.rec + (size_t)(l - 1) * g.N + ((gbase + (size_t)u * 256) << 2)); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!open[u]) continue;
+            const size_t c0 = (gbase + (size_t)u * 256) << 2;
+            if (STATS) loc[0] += __popc(open[u]);
+            if (ETCH) {
+                unsigned o = 0;                                      // empty columns have nothing to etch
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (((open[u] >> j) & 1) && ln[u][j] > 0) o |= 1u << j;
+                if (o) etch_group4<STATS>(g, c0, o, ln[u], dz, matId, isAll, pre[u], loc[1], loc[2]);
+            } else depo_group4<STATS>(g, c0, open[u], ln[u], dz, matId, pre[u], flags, loc[1], loc[2]);
+        }
+    }
+    if (STATS) {
+        if (ETCH) { const int slot[3] = {ST_OPEN, ST_ETCHED, ST_REMOVED}; stats_commit<3>(gstats, loc, slot); }
+        else { const int slot[3] = {ST_OPEN, ST_EXTEND, ST_APPEND}; stats_commit<3>(gstats, loc, slot); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -170,28 +403,47 @@ __global__ __launch_bounds__(256) void k_etch_vertical(GridView g, const uint8_t
 
 template <bool ETCH>
 __global__ __launch_bounds__(256) void k_snapshot_tops(GridView g, const uint8_t* __restrict__ mask, int matId, int R,
-                                                       uint16_t* __restrict__ topq, uint8_t* __restrict__ eflag,
-                                                       int* __restrict__ flags) {
+                                                       uint16_t* __restrict__ topq, uint8_t* __restrict__ eflag) {
     const bool isAll = (matId == 255);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t off = (size_t)R * g.ny;
-    int any = 0;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
-        int l = g.len[c];
-        uint16_t q = 0; int ok = 0;
-        if (l > 0) {
-            size_t top = (size_t)(l - 1) * g.N + c;
-            q = g.z1[top];
-            if (ETCH) ok = isAll || (g.mat[top] == matId);
+        const int l = g.len[c];
+        const uint32_t r = l > 0 ? g.rec[(size_t)(l - 1) * g.N + c] : 0;
+        topq[off + c] = (uint16_t)rec_z1(r);
+        if (ETCH) eflag[off + c] = ((!mask || mask[c]) && l > 0 && (isAll || rec_mat(r) == matId)) ? 1 : 0;
+    }
+}
+
+template <bool ETCH>
+__global__ __launch_bounds__(256) void k_snapshot_tops_g4(GridView g, const uint8_t* __restrict__ mask, int matId, int R,
+                                                          uint16_t* __restrict__ topq, uint8_t* __restrict__ eflag) {
+    const bool isAll = (matId == 255);
+    const size_t ngroups = g.N >> 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t off = (size_t)R * g.ny;
+    for (size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += stride) {
+        const size_t c0 = gi << 2;
+        const u8x4 ln = ld_u8x4(g.len + c0);
+        const int l = ln[0];
+        u32x4 tv = (u32x4)(0);
+        if (as_u32(ln) == as_u32(splat4(l))) { if (l > 0) tv = ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0); }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int lj = ln[j]; if (lj > 0) tv[j] = g.rec[(size_t)(lj - 1) * g.N + c0 + j]; }
         }
-        topq[off + c] = q;
+        u16x4 q;
+#pragma unroll
+        for (int j = 0; j < 4; j++) q[j] = (unsigned short)rec_z1(tv[j]);
+        *(u16x4*)(topq + off + c0) = q;
         if (ETCH) {
-            int e = ((!mask || mask[c]) && ok) ? 1 : 0;
-            eflag[off + c] = (uint8_t)e;
-            any |= e;
+            const u8x4 mk = mask ? ld_u8x4(mask + c0) : splat4(1);
+            u8x4 e;
+#pragma unroll
+            for (int j = 0; j < 4; j++) e[j] = (mk[j] && ln[j] > 0 && (isAll || rec_mat(tv[j]) == matId)) ? 1 : 0;
+            st_u8x4(eflag + off + c0, e);
         }
     }
-    if (ETCH && any) flags[1] = 1;          // "some column is etchable" (cg1:692)
 }
 
 // rows to send: first R rows -> lower neighbour, last R rows -> upper neighbour.
@@ -240,8 +492,8 @@ __global__ __launch_bounds__(256) void k_halo_unpack(uint16_t* __restrict__ topq
 // increment of the ellipsoidal kernel (cg1:324-357).
 struct Tap { int off; float add; };
 
-// Stencil tile geometry: a block of 256 threads updates TI x TJ columns; thread (tx, ty)
-// owns column j = tx and the TI/4 rows ty, ty+4, ...
+// Geometry of the general stencil kernel: a block of 256 threads updates TI x TJ columns;
+// thread (tx, ty) owns column j = tx and the TI/4 rows ty, ty+4, ...
 constexpr int TJ = 64;
 constexpr int TI = 16;
 constexpr int ROWS_PER_THREAD = TI / 4;
@@ -255,6 +507,8 @@ __host__ __device__ inline size_t stencil_lds_bytes(int R) { return (size_t)(TI 
 // increment is a multiple of 2^-40 (heights are < 2^13 and multiples of 2^-40 as well, so the
 // sum fits 53 bits).  The host sorts taps into `taps` (safe, done in float32) and `taps64`
 // (increment too fine, done in double exactly like the reference).
+//
+// General form: any radius that fits the LDS, tap list at run time, one column at a time.
 template <bool ETCH, bool STATS>
 __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t* __restrict__ mask, int matId, double t, int R,
                                                        const uint16_t* __restrict__ topq, const uint8_t* __restrict__ eflag,
@@ -267,7 +521,6 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
     const int tiles_j = (g.ny + TJ - 1) / TJ;
     const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x % tiles_j;
     const int i_base = tile_i * TI, j_base = tile_j * TJ;
-    const float zsf_dummy = 0.f; (void)zsf_dummy;
 
     // ---- stage heights (as float32 of q*zscale, cg1:465) with halo; flags fold into +inf
     for (int e = threadIdx.x; e < tile_rows * pitch; e += 256) {
@@ -348,19 +601,8 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 size_t c = (size_t)il * g.ny + j;
                 int l = g.len[c];
                 if (ETCH) {
-                    // floor: bottom of the top run of matId (cg1:646-660); 0 for ALL
                     float F = 0.f;
-                    if (!isAll && l > 0) {
-                        double floorZ = (double)g.z0[(size_t)(l - 1) * g.N + c] * g.zs;
-                        if (STATS) loc[3]++;
-                        for (int s = l - 2; s >= 0; s--) {
-                            size_t b = (size_t)s * g.N + c;
-                            if (g.mat[b] != matId) break;
-                            floorZ = (double)g.z0[b] * g.zs;
-                            if (STATS) loc[3]++;
-                        }
-                        F = (float)fmax(0.0, floorZ);
-                    }
+                    if (!isAll && l > 0) F = (float)fmax(0.0, floor_of_top_run(g, c, l, matId, loc[3]));
                     float hp = fmaxf(0.f, fmaxf(F, m[r]));             // cg1:725
                     double dz = (double)own[r] - (double)hp;
                     if (dz > CG_EPS) {
@@ -371,7 +613,7 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 } else {
                     if (only_len >= 0) {
                         if (l != only_len) continue;
-                        if (l > 0 && g.mat[(size_t)(l - 1) * g.N + c] == matId) continue;
+                        if (l > 0 && rec_mat(g.rec[(size_t)(l - 1) * g.N + c]) == matId) continue;
                     }
                     double dz = (double)m[r] - (double)own[r];         // cg1:534-536
                     if (STATS) loc[0]++;
@@ -380,6 +622,193 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                     if (rr == 3) flags[0] = 1;
                     if (STATS) { loc[1] += (rr == 1); loc[2] += (rr == 2); }
                 }
+            }
+        }
+    }
+    if (STATS) {
+        if (ETCH) { const int slot[4] = {ST_OPEN, ST_ETCHED, ST_REMOVED, ST_FLOOR}; stats_commit<4>(gstats, loc, slot); }
+        else { const int slot[4] = {ST_OPEN, ST_EXTEND, ST_APPEND, ST_FLOOR}; stats_commit<4>(gstats, loc, slot); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// lateral-stencil steps, 4 columns per thread, radius known at compile time
+// ------------------------------------------------------------------------------------------
+// The ellipsoidal kernel is symmetric in +-du and +-dv (script_columngrid.js:337-347 computes
+// add from du*du and dv*dv), so one quadrant table of (R+1)^2 increments describes it; entries
+// outside the ellipse, and entries that need double evaluation, hold -infinity so that they
+// never win.  max(h1,h2,h3,h4)+a == max(h1+a,...,h4+a) exactly because rounding is monotone:
+// one add and one max serve four taps.
+template <int R> struct AddTab { float a[(R + 1) * (R + 1)]; };
+
+// Tile of the symmetric kernel: TJS columns x (1024 / TJS) rows per block of 256 threads.
+template <int R, int TJS> struct SymGeom {
+    static constexpr int TIS = 1024 / TJS;           // rows per block
+    static constexpr int GX = TJS / 4;               // groups (threads) per row
+    static constexpr int Rp = (R + 3) & ~3;          // halo columns rounded up to whole groups
+    static constexpr int PITCH = TJS + 2 * Rp;       // floats per LDS row
+    static constexpr int ROWS = TIS + 2 * R;
+    static constexpr int W = 4 + 2 * Rp;             // floats a thread reads per row
+    static constexpr int GPR = PITCH / 4;            // groups per LDS row
+};
+
+// Thread (gx, ry) updates columns j0..j0+3 of row ry of the block's tile.
+// Rimg = halo rows of the snapshot image (the cached kernel's Rx, >= R).
+template <int R, int TJS, bool ETCH, bool STATS>
+__global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* __restrict__ mask, int matId, double t, int Rimg,
+                                                     const uint16_t* __restrict__ topq, const uint8_t* __restrict__ eflag,
+                                                     const AddTab<R> tab, const Tap* __restrict__ taps64, int ntaps64,
+                                                     int* __restrict__ flags, unsigned long long* gstats) {
+    using G = SymGeom<R, TJS>;
+    constexpr int Rp = G::Rp, PITCH = G::PITCH, ROWS = G::ROWS, W = G::W, GPR = G::GPR, TIS = G::TIS, GX = G::GX;
+    __shared__ __align__(16) float s_h[ROWS * PITCH];
+    const int tiles_j = (g.ny + TJS - 1) / TJS;
+    const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x - tile_i * tiles_j;
+    const int i_base = tile_i * TIS, j_base = tile_j * TJS;
+    const float INF = __builtin_inff();
+
+    // ---- stage float32(q*zscale) (cg1:465) with halo; not-etchable cells become +inf (cg1:718)
+    for (int e = threadIdx.x; e < ROWS * GPR; e += 256) {
+        const int r = e / GPR, gq = e - r * GPR;
+        const int irow = i_base + r + (Rimg - R);
+        const int j4 = j_base - Rp + 4 * gq;
+        float4 h;
+        if (irow >= g.nx + 2 * Rimg) { const float v = ETCH ? INF : 0.f; h = make_float4(v, v, v, v); }
+        else {
+            const bool left = j4 < 0, right = j4 >= g.ny;
+            const int jc = left ? 0 : (right ? g.ny - 4 : j4);
+            const size_t p = (size_t)irow * g.ny + jc;
+            u16x4 q = *(const u16x4*)(topq + p);
+            if (left) q = (u16x4)(q[0]);               // clamp-replicate in j (cg1:374-380)
+            if (right) q = (u16x4)(q[3]);
+            h.x = (float)((double)q[0] * g.zs); h.y = (float)((double)q[1] * g.zs);
+            h.z = (float)((double)q[2] * g.zs); h.w = (float)((double)q[3] * g.zs);
+            if (ETCH) {
+                if (left || right) h = make_float4(INF, INF, INF, INF);      // flags are zero outside the domain (cg1:671)
+                else {
+                    const u8x4 e4 = ld_u8x4(eflag + p);
+                    if (!e4[0]) h.x = INF; if (!e4[1]) h.y = INF; if (!e4[2]) h.z = INF; if (!e4[3]) h.w = INF;
+                }
+            }
+        }
+        *(float4*)(s_h + r * PITCH + 4 * gq) = h;
+    }
+    __syncthreads();
+
+    const int gx = threadIdx.x % GX, ry = threadIdx.x / GX;
+    const int il = i_base + ry, j0 = j_base + 4 * gx;
+    unsigned loc[4] = {0, 0, 0, 0};
+    if (il < g.nx && j0 < g.ny) {
+        const size_t c0 = (size_t)il * g.ny + j0;
+        unsigned act;
+        if (ETCH) act = open_bits(ld_u8x4(eflag + (size_t)(il + Rimg) * g.ny + j0));
+        else act = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
+        if (act) {
+            const float* rowc = s_h + (ry + R) * PITCH + 4 * gx;
+            float hc[W];
+#pragma unroll
+            for (int k = 0; k < W / 4; k++) { const float4 v = *(const float4*)(rowc + 4 * k); hc[4 * k] = v.x; hc[4 * k + 1] = v.y; hc[4 * k + 2] = v.z; hc[4 * k + 3] = v.w; }
+            float own[4], m[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                own[c] = hc[Rp + c];
+                // for etch, own of a non-etchable column is +inf; it is never used (act bit clear)
+                m[c] = ETCH ? (float)((double)own[c] - t) : (float)((double)own[c] + t);     // cg1:702 / cg1:499
+            }
+#define CG_OP(a, b) (ETCH ? fminf((a), (b)) : fmaxf((a), (b)))
+#define CG_ADD(x, a) (ETCH ? ((x) - (a)) : ((x) + (a)))
+            // centre row
+#pragma unroll
+            for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(hc[Rp + c], tab.a[0]));
+#pragma unroll
+            for (int dv = 1; dv <= R; dv++) {
+                const float a = tab.a[dv];
+#pragma unroll
+                for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(CG_OP(hc[Rp + c + dv], hc[Rp + c - dv]), a));
+            }
+            // row pairs +-du: v[k] = op(row+du[k], row-du[k]) is shared by every dv
+#pragma unroll
+            for (int du = 1; du <= R; du++) {
+                float v[W];
+#pragma unroll
+                for (int k = 0; k < W / 4; k++) {
+                    const float4 p = *(const float4*)(rowc + du * PITCH + 4 * k);
+                    const float4 n = *(const float4*)(rowc - du * PITCH + 4 * k);
+                    v[4 * k] = CG_OP(p.x, n.x); v[4 * k + 1] = CG_OP(p.y, n.y); v[4 * k + 2] = CG_OP(p.z, n.z); v[4 * k + 3] = CG_OP(p.w, n.w);
+                }
+                const float a0 = tab.a[du * (R + 1)];
+#pragma unroll
+                for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(v[Rp + c], a0));
+#pragma unroll
+                for (int dv = 1; dv <= R; dv++) {
+                    const float a = tab.a[du * (R + 1) + dv];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(CG_OP(v[Rp + c + dv], v[Rp + c - dv]), a));
+                }
+            }
+            // taps whose increment is too fine for float32: double, like the reference
+            if (ntaps64 > 0) {
+                double md[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) md[c] = (double)m[c];
+                const float* ctr = s_h + (ry + R) * PITCH + Rp + 4 * gx;
+                for (int q = 0; q < ntaps64; q++) {
+                    const int off = taps64[q].off; const double add = (double)taps64[q].add;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const double hv = (double)ctr[c + off];
+                        const double cand = ETCH ? hv - add : hv + add;
+                        if (ETCH) { if (cand < md[c]) md[c] = cand; } else { if (cand > md[c]) md[c] = cand; }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) m[c] = (float)md[c];
+            }
+#undef CG_OP
+#undef CG_ADD
+            // ---- per-column update
+            const u8x4 ln = ld_u8x4(g.len + c0);
+            double dz[4] = {0, 0, 0, 0};
+            unsigned open = 0;
+            Pre4 pre; pre.l = -1;
+            if (STATS) loc[0] += __popc(act);
+            if (!ETCH) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (!((act >> c) & 1)) continue;
+                    const double d = (double)m[c] - (double)own[c];          // cg1:534-537
+                    if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
+                }
+                if (open) depo_group4<STATS>(g, c0, open, ln, dz, matId, pre, flags, loc[1], loc[2]);
+            } else {
+                const bool isAll = (matId == 255);
+                float F[4] = {0.f, 0.f, 0.f, 0.f};
+                const int l = ln[0];
+                const bool uniform = as_u32(ln) == as_u32(splat4(l));
+                if (uniform && l > 0) { pre.l = l; pre.top = ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0); }
+                if (!isAll) {
+                    // floor = bottom of the top run of matId (cg1:646-660)
+                    u32x4 below = (u32x4)(0);
+                    if (uniform && l >= 2) below = ld_rec4(g.rec + (size_t)(l - 2) * g.N + c0);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (!((act >> c) & 1)) continue;
+                        double floorZ;
+                        if (uniform && (l < 2 || (!rec_hole(below[c]) && rec_mat(below[c]) != matId))) {
+                            floorZ = (double)rec_z1(below[c]) * g.zs;         // the usual case: the run is the top layer alone
+                            if (STATS) loc[3]++;
+                        } else floorZ = floor_of_top_run(g, c0 + c, ln[c], matId, loc[3]);
+                        F[c] = (float)fmax(0.0, floorZ);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (!((act >> c) & 1)) continue;
+                    const float hpv = fmaxf(0.f, fmaxf(F[c], m[c]));                  // cg1:725
+                    const double d = (double)own[c] - (double)hpv;
+                    if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
+                }
+                if (open) etch_group4<STATS>(g, c0, open, ln, dz, matId, isAll, pre, loc[1], loc[2]);
             }
         }
     }
@@ -453,7 +882,7 @@ __global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restric
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         int l = g.len[c];
-        if (l > 0) { unsigned q = g.z1[(size_t)(l - 1) * g.N + c]; mq = q > mq ? q : mq; ml = (unsigned)l > ml ? (unsigned)l : ml; }
+        if (l > 0) { unsigned q = rec_z1(g.rec[(size_t)(l - 1) * g.N + c]); mq = q > mq ? q : mq; ml = (unsigned)l > ml ? (unsigned)l : ml; }
     }
     for (int o = 32; o > 0; o >>= 1) {
         unsigned a = __shfl_down(mq, o, 64), b = __shfl_down(ml, o, 64);
@@ -469,18 +898,26 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     return x ^ (x >> 31);
 }
 
+// checksum over the reference's view of the columns: len counts layers (not gaps) and every
+// layer contributes (mat, z0q, z1q)
 __global__ __launch_bounds__(256) void k_checksum(GridView g, unsigned long long* __restrict__ out) {
     unsigned long long sum = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         unsigned long long gc = (unsigned long long)g.i0 * g.ny + c;
-        int l = g.len[c];
+        const int l = min((int)g.len[c], g.lmax);
+        int layers = 0;
+        for (int k = 0; k < l; k++) layers += !rec_hole(g.rec[(size_t)k * g.N + c]);
         unsigned long long h = splitmix64(gc);
-        h = splitmix64(h ^ (unsigned long long)l);
-        for (int k = 0; k < l && k < g.lmax; k++) {
-            size_t b = (size_t)k * g.N + c;
-            unsigned long long v = (unsigned long long)g.mat[b] | ((unsigned long long)g.z0[b] << 8) | ((unsigned long long)g.z1[b] << 24);
-            h = splitmix64(h ^ v);
+        h = splitmix64(h ^ (unsigned long long)layers);
+        unsigned prev = 0;
+        for (int k = 0; k < l; k++) {
+            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            if (!rec_hole(r)) {
+                unsigned long long v = (unsigned long long)rec_mat(r) | ((unsigned long long)prev << 8) | ((unsigned long long)rec_z1(r) << 24);
+                h = splitmix64(h ^ v);
+            }
+            prev = rec_z1(r);
         }
         sum += h;
     }
@@ -489,45 +926,58 @@ __global__ __launch_bounds__(256) void k_checksum(GridView g, unsigned long long
 }
 
 // ------------------------------------------------------------------------------------------
-// layout conversion: plane-major device planes <-> the reference's column-major host layout
+// layout conversion: device intervals <-> the reference's column-major host layout
 // ------------------------------------------------------------------------------------------
 // Gather `ncols` columns (column s of the output is device column col0 + s*col_stride) into
-// reference layout with stride L: omat[s*L+k], ozp[2*(s*L+k)+{0,1}], olen[s].
+// reference layout with stride L: omat[s*L+k], ozp[2*(s*L+k)+{0,1}], olen[s]; gaps are skipped,
+// slots at and above the layer count are zero.
 __global__ __launch_bounds__(256) void k_gather_columns(GridView g, size_t col0, size_t col_stride, size_t ncols, int L,
                                                         uint8_t* __restrict__ omat, uint16_t* __restrict__ ozp, uint8_t* __restrict__ olen) {
-    // thread -> (column s, layer k) with k fastest so that the writes are contiguous
-    const size_t total = ncols * (size_t)L;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        size_t s = e / L; int k = (int)(e - s * L);
-        size_t c = col0 + s * col_stride;
-        uint8_t m = 0; uint16_t a = 0, b = 0;
-        if (k < g.lmax) { size_t p = (size_t)k * g.N + c; m = g.mat[p]; a = g.z0[p]; b = g.z1[p]; }
-        omat[e] = m; ozp[2 * e] = a; ozp[2 * e + 1] = b;
-        if (k == 0) olen[s] = g.len[c];
+    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < ncols; s += stride) {
+        const size_t c = col0 + s * col_stride;
+        const int l = min((int)g.len[c], g.lmax);
+        int w = 0; unsigned prev = 0;
+        for (int k = 0; k < l; k++) {
+            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            if (!rec_hole(r) && w < L) {
+                const size_t o = s * (size_t)L + w;
+                omat[o] = (uint8_t)rec_mat(r); ozp[2 * o] = (uint16_t)prev; ozp[2 * o + 1] = (uint16_t)rec_z1(r);
+                w++;
+            }
+            prev = rec_z1(r);
+        }
+        olen[s] = (uint8_t)w;
+        for (int k = w; k < L; k++) { const size_t o = s * (size_t)L + k; omat[o] = 0; ozp[2 * o] = 0; ozp[2 * o + 1] = 0; }
     }
 }
 
-// inverse of k_gather_columns for a contiguous column range; also reports whether any column
-// has a vertical gap (z0 of a layer above the z1 below it, or z0[0] > 0), flags[2]
+// Inverse of k_gather_columns for a contiguous column range.  A layer that starts above the
+// top of the one below becomes a gap interval + the layer.  flags[2]: some column has a gap;
+// flags[3]: a column needs more planes than provisioned (the largest need); flags[1]: a layer
+// starts below the top of the one under it (cannot be represented).
 __global__ __launch_bounds__(256) void k_scatter_columns(GridView g, size_t col0, size_t ncols, int L,
                                                          const uint8_t* __restrict__ imat, const uint16_t* __restrict__ izp,
                                                          const uint8_t* __restrict__ ilen, int* __restrict__ flags) {
-    const size_t total = ncols * (size_t)g.lmax;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        size_t s = e / g.lmax; int k = (int)(e - s * g.lmax);
-        size_t c = col0 + s;
-        uint8_t m = 0; uint16_t a = 0, b = 0;
-        if (k < L) { size_t p = s * (size_t)L + k; m = imat[p]; a = izp[2 * p]; b = izp[2 * p + 1]; }
-        size_t p = (size_t)k * g.N + c;
-        g.mat[p] = m; g.z0[p] = a; g.z1[p] = b;
-        int l = ilen[s];
-        if (k == 0) g.len[c] = (uint8_t)l;
-        if (k < l && k < L) {
-            unsigned below = (k == 0) ? 0u : izp[2 * (s * (size_t)L + k - 1) + 1];
-            if ((double)a * g.zs > (double)below * g.zs + CG_EPS) flags[2] = 1;
+    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < ncols; s += stride) {
+        const size_t c = col0 + s;
+        const int l = min((int)ilen[s], L);
+        int w = 0; unsigned prev = 0;
+        for (int k = 0; k < l; k++) {
+            const size_t p = s * (size_t)L + k;
+            const unsigned z0 = izp[2 * p], z1 = izp[2 * p + 1];
+            if (z0 > prev) {
+                if (w < g.lmax) g.rec[(size_t)w * g.N + c] = (z0 & 0xffffu) | REC_HOLE;
+                w++; flags[2] = 1;
+            } else if (z0 < prev) flags[1] = 1;
+            if (w < g.lmax) g.rec[(size_t)w * g.N + c] = rec_make(z1, imat[p]);
+            w++;
+            prev = z1;
         }
+        if (w > g.lmax) atomicMax(&flags[3], w);
+        g.len[c] = (uint8_t)min(w, g.lmax);
+        for (int k = min(w, g.lmax); k < g.lmax; k++) g.rec[(size_t)k * g.N + c] = 0;
     }
 }
 

@@ -18,6 +18,19 @@
 
 using namespace cgk;
 
+// groups of 4 columns in flight per thread in the vertical kernels (tuning knob: env CG_VU = 1, 2, 4)
+static int vu_setting() {
+    static int v = [] { const char* e = getenv("CG_VU"); int x = e ? atoi(e) : 4; return (x == 1 || x == 2 || x == 4) ? x : 4; }();
+    return v;
+}
+template <bool ETCH>
+static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t);
+// columns per tile row of the symmetric stencil kernel (tuning knob: env CG_TJS = 64, 128, 256)
+static int sym_tile_cols() {
+    static int v = [] { const char* e = getenv("CG_TJS"); int x = e ? atoi(e) : 256; return (x == 64 || x == 128 || x == 256) ? x : 256; }();
+    return v;
+}
+
 namespace {
 
 thread_local std::string t_create_error;
@@ -33,10 +46,14 @@ struct ConfKernel {
     Tap* d_taps = nullptr;  int ntaps = 0;       // float32-exact taps
     Tap* d_taps64 = nullptr; int ntaps64 = 0;    // taps that must be evaluated in double
     int dev_R = -1;                              // pitch the device offsets were built for
+    // symmetric form for k_stencil_sym: effective radius, quadrant table, fine taps at its pitch
+    int Re = 0; bool sym_ok = false;
+    std::vector<float> quad;                     // (Re+1)^2 increments, -inf = not a float32 tap
+    Tap* d_taps64_sym = nullptr; int ntaps64_sym = 0;
 };
 
 struct Snapshot {
-    uint8_t* len = nullptr; uint8_t* mat = nullptr; uint16_t* z0 = nullptr; uint16_t* z1 = nullptr;
+    uint8_t* len = nullptr; uint32_t* rec = nullptr;
     int lmax = 0; int len_bound = 0; bool has_gaps = false;
 };
 
@@ -56,7 +73,7 @@ struct cg_grid {
     size_t N = 0;
     double dx = 0, dy = 0, zscale = 0.1;
     int lmax = 32;
-    uint8_t* len = nullptr; uint8_t* mat = nullptr; uint16_t* z0 = nullptr; uint16_t* z1 = nullptr;
+    uint8_t* len = nullptr; uint32_t* rec = nullptr;      // see cg_kernels.hip.h for the layout
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<uint8_t*> masks;
     std::deque<ConfKernel*> kcache;
@@ -138,8 +155,8 @@ int js_to_int32(double v) {                  // (v | 0)
 
 GridView view(const cg_grid* g) {
     GridView v;
-    v.len = g->len; v.mat = g->mat; v.z0 = g->z0; v.z1 = g->z1;
-    v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.zs = g->zscale;
+    v.len = g->len; v.rec = g->rec;
+    v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
     return v;
 }
 
@@ -150,19 +167,15 @@ unsigned blocks_for(size_t n) {
 
 void free_planes(cg_grid* g) {
     if (g->len) (void)hipFree(g->len);
-    if (g->mat) (void)hipFree(g->mat);
-    if (g->z0) (void)hipFree(g->z0);
-    if (g->z1) (void)hipFree(g->z1);
-    g->len = g->mat = nullptr; g->z0 = g->z1 = nullptr;
+    if (g->rec) (void)hipFree(g->rec);
+    g->len = nullptr; g->rec = nullptr;
 }
 
 int alloc_planes(cg_grid* g, int lmax) {
     free_planes(g);
     size_t S = g->N * (size_t)lmax;
-    HIPCHK(g, hipMalloc(&g->len, std::max<size_t>(g->N, 1)));
-    HIPCHK(g, hipMalloc(&g->mat, std::max<size_t>(S, 1)));
-    HIPCHK(g, hipMalloc(&g->z0, std::max<size_t>(2 * S, 2)));
-    HIPCHK(g, hipMalloc(&g->z1, std::max<size_t>(2 * S, 2)));
+    HIPCHK(g, hipMalloc(&g->len, std::max<size_t>(g->N, 4)));
+    HIPCHK(g, hipMalloc(&g->rec, std::max<size_t>(4 * S, 4)));
     g->lmax = lmax;
     return CG_OK;
 }
@@ -176,29 +189,24 @@ int zero_planes(cg_grid* g, bool all = true) {
     size_t S = g->N * (size_t)planes;
     HIPCHK(g, hipMemsetAsync(g->len, 0, g->N, g->stream));
     if (S == 0) { g->len_bound = 0; g->has_gaps = false; return CG_OK; }
-    HIPCHK(g, hipMemsetAsync(g->mat, 0, S, g->stream));
-    HIPCHK(g, hipMemsetAsync(g->z0, 0, 2 * S, g->stream));
-    HIPCHK(g, hipMemsetAsync(g->z1, 0, 2 * S, g->stream));
+    HIPCHK(g, hipMemsetAsync(g->rec, 0, 4 * S, g->stream));
     g->len_bound = 0; g->has_gaps = false;
     return CG_OK;
 }
 
 // _expandBuffers (script_columngrid.js:129-168): Lmax += 16.  Plane-major storage makes the old
 // contents a prefix of the new allocation: one copy per array, no re-striding.
-int grow_planes(cg_grid* g) {
-    const int newL = g->lmax + 16;
+int grow_planes(cg_grid* g, int add = 16) {
+    const int newL = std::min(256, g->lmax + add);
+    if (newL == g->lmax) return CG_OK;
     size_t So = g->N * (size_t)g->lmax, Sn = g->N * (size_t)newL;
-    uint8_t* nm = nullptr; uint16_t *n0 = nullptr, *n1 = nullptr;
-    HIPCHK(g, hipMalloc(&nm, Sn)); HIPCHK(g, hipMalloc(&n0, 2 * Sn)); HIPCHK(g, hipMalloc(&n1, 2 * Sn));
-    HIPCHK(g, hipMemcpyAsync(nm, g->mat, So, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(n0, g->z0, 2 * So, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(n1, g->z1, 2 * So, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemsetAsync(nm + So, 0, Sn - So, g->stream));
-    HIPCHK(g, hipMemsetAsync(n0 + So, 0, 2 * (Sn - So), g->stream));
-    HIPCHK(g, hipMemsetAsync(n1 + So, 0, 2 * (Sn - So), g->stream));
+    uint32_t* nr = nullptr;
+    HIPCHK(g, hipMalloc(&nr, 4 * Sn));
+    HIPCHK(g, hipMemcpyAsync(nr, g->rec, 4 * So, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemsetAsync(nr + So, 0, 4 * (Sn - So), g->stream));
     HIPCHK(g, hipStreamSynchronize(g->stream));
-    (void)hipFree(g->mat); (void)hipFree(g->z0); (void)hipFree(g->z1);
-    g->mat = nm; g->z0 = n0; g->z1 = n1; g->lmax = newL;
+    (void)hipFree(g->rec);
+    g->rec = nr; g->lmax = newL;
     return CG_OK;
 }
 
@@ -234,6 +242,7 @@ void stats_begin(cg_grid* g) {
 void free_kernel(ConfKernel* k) {
     if (k->d_taps) (void)hipFree(k->d_taps);
     if (k->d_taps64) (void)hipFree(k->d_taps64);
+    if (k->d_taps64_sym) (void)hipFree(k->d_taps64_sym);
     delete k;
 }
 
@@ -282,6 +291,48 @@ int upload_taps(cg_grid* g, ConfKernel* k, int R) {
     if (!safe.empty()) HIPCHK(g, hipMemcpy(k->d_taps, safe.data(), safe.size() * sizeof(Tap), hipMemcpyHostToDevice));
     if (!fine.empty()) HIPCHK(g, hipMemcpy(k->d_taps64, fine.data(), fine.size() * sizeof(Tap), hipMemcpyHostToDevice));
     k->ntaps = (int)safe.size(); k->ntaps64 = (int)fine.size(); k->dev_R = R;
+
+    // symmetric quadrant form (k_stencil_sym): usable when the effective radius is 1..8 and the
+    // four mirror images of every tap exist with the very same increment
+    int Re = 0;
+    for (size_t q = 0; q < k->add.size(); q++) Re = std::max(Re, std::max(std::abs(k->du[q]), std::abs(k->dv[q])));
+    k->Re = Re; k->sym_ok = false;
+    if (Re >= 1 && Re <= 8) {
+        const int n = Re + 1;
+        std::vector<float> quad(n * n, -INFINITY);
+        std::vector<int> seen(n * n, 0);
+        bool ok = true;
+        std::vector<Tap> fine_sym;
+        const int pitch_sym = sym_tile_cols() + 2 * ((Re + 3) & ~3);
+        for (size_t q = 0; q < k->add.size() && ok; q++) {
+            const int a = std::abs(k->du[q]), b = std::abs(k->dv[q]);
+            const double scaled = std::ldexp((double)k->add[q], 40);
+            const bool is_safe = scaled == std::floor(scaled);
+            if (!seen[a * n + b]) {
+                seen[a * n + b] = 1;
+                if (is_safe) quad[a * n + b] = k->add[q];
+            }
+            uint32_t b0, b1; float ref = k->add[q];
+            // all mirror images must carry the same bits
+            for (size_t r = 0; r < k->add.size(); r++)
+                if (std::abs(k->du[r]) == a && std::abs(k->dv[r]) == b) { memcpy(&b0, &k->add[r], 4); memcpy(&b1, &ref, 4); if (b0 != b1) ok = false; }
+            seen[a * n + b] += 1;
+            if (!is_safe) { Tap tp; tp.off = k->du[q] * pitch_sym + k->dv[q]; tp.add = k->add[q]; fine_sym.push_back(tp); }
+        }
+        // every quadrant entry must have been seen 1 (centre), 2 (axes) or 4 times
+        for (int a = 0; a <= Re && ok; a++) for (int b = 0; b <= Re; b++) {
+            const int cnt = seen[a * n + b] ? seen[a * n + b] - 1 : 0;
+            const int want = (a == 0 && b == 0) ? 1 : ((a == 0 || b == 0) ? 2 : 4);
+            if (cnt != 0 && cnt != want) ok = false;
+        }
+        if (ok) {
+            k->quad = quad; k->sym_ok = true;
+            if (k->d_taps64_sym) { (void)hipFree(k->d_taps64_sym); k->d_taps64_sym = nullptr; }
+            HIPCHK(g, hipMalloc(&k->d_taps64_sym, std::max<size_t>(1, fine_sym.size()) * sizeof(Tap)));
+            if (!fine_sym.empty()) HIPCHK(g, hipMemcpy(k->d_taps64_sym, fine_sym.data(), fine_sym.size() * sizeof(Tap), hipMemcpyHostToDevice));
+            k->ntaps64_sym = (int)fine_sym.size();
+        }
+    }
     return CG_OK;
 }
 
@@ -315,16 +366,20 @@ int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
     if (may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
     const dim3 grid(blocks_for(g->N)), blk(256);
     ProfScope ps(g, CG_K_DEPO_VERTICAL);
-    if (g->stats_on) hipLaunchKernelGGL(k_depo_vertical<true>, grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
-    else hipLaunchKernelGGL(k_depo_vertical<false>, grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
+    if (g->N % 4 == 0) {        // 4 columns per thread
+        launch_vertical<false>(g, mask, mat, t);
+    } else {
+        if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<false, true>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
+        else hipLaunchKernelGGL((k_vertical_1<false, false>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
+    }
     HIPCHK(g, hipGetLastError());
     if (may_overflow) {
         int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
         if (fl[0]) {
             const int oldL = g->lmax;
             rc = grow_planes(g); if (rc) return rc;
-            if (g->stats_on) hipLaunchKernelGGL(k_depo_vertical<true>, grid, blk, 0, g->stream, view(g), mask, mat, t, oldL, g->d_flags, g->d_stats);
-            else hipLaunchKernelGGL(k_depo_vertical<false>, grid, blk, 0, g->stream, view(g), mask, mat, t, oldL, g->d_flags, g->d_stats);
+            if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<false, true>), grid, blk, 0, g->stream, view(g), mask, mat, t, oldL, g->d_flags, g->d_stats);
+            else hipLaunchKernelGGL((k_vertical_1<false, false>), grid, blk, 0, g->stream, view(g), mask, mat, t, oldL, g->d_flags, g->d_stats);
             HIPCHK(g, hipGetLastError());
         }
     }
@@ -337,6 +392,32 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
     const size_t lds = stencil_lds_bytes(R);
     const dim3 grid(tiles), blk(256);
     ProfScope ps(g, etch ? CG_K_STENCIL_ETCH : CG_K_STENCIL_DEPOSIT);
+    if (only_len < 0 && K->sym_ok && g->ny % 4 == 0 && !getenv("CG_NO_SYM")) {
+        const int tjs = sym_tile_cols();
+#define SYM(RR, TT, E, S)                                                                                      \
+    do {                                                                                                       \
+        AddTab<RR> tab; memcpy(tab.a, K->quad.data(), sizeof tab.a);                                           \
+        const int tis = 1024 / TT;                                                                             \
+        const dim3 gridS(((g->nx + tis - 1) / tis) * ((g->ny + TT - 1) / TT));                                 \
+        hipLaunchKernelGGL((k_stencil_sym<RR, TT, E, S>), gridS, blk, 0, g->stream, view(g), mask, mat, t_eff, R, g->topq, g->eflag, \
+                           tab, K->d_taps64_sym, K->ntaps64_sym, g->d_flags, g->d_stats);                      \
+    } while (0)
+#define SYM_T(RR, E, S) do { if (tjs == 64) SYM(RR, 64, E, S); else if (tjs == 128) SYM(RR, 128, E, S); else SYM(RR, 256, E, S); } while (0)
+#define SYM_ES(RR)                                                                                             \
+    do {                                                                                                       \
+        if (etch) { if (g->stats_on) SYM_T(RR, true, true); else SYM_T(RR, true, false); }                     \
+        else { if (g->stats_on) SYM_T(RR, false, true); else SYM_T(RR, false, false); }                        \
+    } while (0)
+        switch (K->Re) {
+        case 1: SYM_ES(1); break; case 2: SYM_ES(2); break; case 3: SYM_ES(3); break; case 4: SYM_ES(4); break;
+        case 5: SYM_ES(5); break; case 6: SYM_ES(6); break; case 7: SYM_ES(7); break; default: SYM_ES(8); break;
+        }
+#undef SYM_ES
+#undef SYM_T
+#undef SYM
+        HIPCHK(g, hipGetLastError());
+        return CG_OK;
+    }
 #define LAUNCH(E, S)                                                                                           \
     do {                                                                                                       \
         if (lds > 48 * 1024)                                                                                   \
@@ -352,6 +433,16 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
 }
 
 }  // namespace
+
+template <bool ETCH>
+static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
+    const int U = vu_setting();
+    const dim3 grid(blocks_for(g->N / 4 / U)), blk(256);
+#define LV(S, UU) hipLaunchKernelGGL((k_vertical_g4<ETCH, S, UU>), grid, blk, 0, g->stream, view(g), mask, mat, t, g->d_flags, g->d_stats)
+    if (g->stats_on) { if (U == 1) LV(true, 1); else if (U == 2) LV(true, 2); else LV(true, 4); }
+    else { if (U == 1) LV(false, 1); else if (U == 2) LV(false, 2); else LV(false, 4); }
+#undef LV
+}
 
 // =============================================================================================
 extern "C" {
@@ -411,7 +502,7 @@ int cg_destroy(cg_grid* g) {
     free_planes(g);
     for (auto m : g->masks) if (m) (void)hipFree(m);
     for (auto k : g->kcache) free_kernel(k);
-    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.mat); (void)hipFree(s.second.z0); (void)hipFree(s.second.z1); }
+    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.rec); }
     if (g->topq) (void)hipFree(g->topq);
     if (g->eflag) (void)hipFree(g->eflag);
     if (!g->halo_external) for (auto h : g->halo) if (h) (void)hipFree(h);
@@ -553,8 +644,10 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
         if (kind == CG_STENCIL_DEPOSIT) return run_depo_vertical(g, mask, mat, t);
         const dim3 grid(blocks_for(g->N)), blk(256);
         ProfScope ps(g, CG_K_ETCH_VERTICAL);
-        if (g->stats_on) hipLaunchKernelGGL(k_etch_vertical<true>, grid, blk, 0, g->stream, view(g), mask, mat, t, g->d_stats);
-        else hipLaunchKernelGGL(k_etch_vertical<false>, grid, blk, 0, g->stream, view(g), mask, mat, t, g->d_stats);
+        if (g->N % 4 == 0) {    // 4 columns per thread
+            launch_vertical<true>(g, mask, mat, t);
+        } else if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<true, true>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
+        else hipLaunchKernelGGL((k_vertical_1<true, false>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
         HIPCHK(g, hipGetLastError());
         return CG_OK;
     }
@@ -571,11 +664,14 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     const dim3 grid(blocks_for(g->N)), blk(256);
     {
         ProfScope ps(g, CG_K_SNAPSHOT);
-        if (kind == CG_STENCIL_ETCH) {
-            HIPCHK(g, hipMemsetAsync(g->d_flags + 1, 0, sizeof(int), g->stream));
-            hipLaunchKernelGGL(k_snapshot_tops<true>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag, g->d_flags);
+        if (g->N % 4 == 0) {
+            const dim3 grid4(blocks_for(g->N / 4));
+            if (kind == CG_STENCIL_ETCH) hipLaunchKernelGGL(k_snapshot_tops_g4<true>, grid4, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag);
+            else hipLaunchKernelGGL(k_snapshot_tops_g4<false>, grid4, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag);
+        } else if (kind == CG_STENCIL_ETCH) {
+            hipLaunchKernelGGL(k_snapshot_tops<true>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag);
         } else {
-            hipLaunchKernelGGL(k_snapshot_tops<false>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag, g->d_flags);
+            hipLaunchKernelGGL(k_snapshot_tops<false>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag);
         }
     }
     HIPCHK(g, hipGetLastError());
@@ -704,7 +800,7 @@ int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
     HIPCHK(g, hipMalloc(&dm, chunk * L)); HIPCHK(g, hipMalloc(&dz, chunk * L * 4)); HIPCHK(g, hipMalloc(&dl, chunk));
     for (size_t c0 = 0; c0 < g->N; c0 += chunk) {
         size_t n = std::min(chunk, g->N - c0);
-        hipLaunchKernelGGL(k_gather_columns, dim3(blocks_for(n * L)), dim3(256), 0, g->stream, view(g), c0, (size_t)1, n, L, dm, dz, dl);
+        hipLaunchKernelGGL(k_gather_columns, dim3(blocks_for(n)), dim3(256), 0, g->stream, view(g), c0, (size_t)1, n, L, dm, dz, dl);
         HIPCHK(g, hipGetLastError());
         HIPCHK(g, hipMemcpyAsync(mat + c0 * L, dm, n * L, hipMemcpyDeviceToHost, g->stream));
         HIPCHK(g, hipMemcpyAsync(zpair + 2 * c0 * L, dz, n * L * 4, hipMemcpyDeviceToHost, g->stream));
@@ -725,18 +821,26 @@ int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8
     const size_t chunk = std::min<size_t>(g->N, (size_t)1 << 20);
     uint8_t *dm = nullptr, *dl = nullptr; uint16_t* dz = nullptr;
     HIPCHK(g, hipMalloc(&dm, chunk * L)); HIPCHK(g, hipMalloc(&dz, chunk * L * 4)); HIPCHK(g, hipMalloc(&dl, chunk));
-    HIPCHK(g, hipMemsetAsync(g->d_flags + 2, 0, sizeof(int), g->stream));
-    for (size_t c0 = 0; c0 < g->N; c0 += chunk) {
-        size_t n = std::min(chunk, g->N - c0);
-        HIPCHK(g, hipMemcpyAsync(dm, mat + c0 * L, n * L, hipMemcpyHostToDevice, g->stream));
-        HIPCHK(g, hipMemcpyAsync(dz, zpair + 2 * c0 * L, n * L * 4, hipMemcpyHostToDevice, g->stream));
-        HIPCHK(g, hipMemcpyAsync(dl, len + c0, n, hipMemcpyHostToDevice, g->stream));
-        hipLaunchKernelGGL(k_scatter_columns, dim3(blocks_for(n * L)), dim3(256), 0, g->stream, view(g), c0, n, L, dm, dz, dl, g->d_flags);
-        HIPCHK(g, hipGetLastError());
-        HIPCHK(g, hipStreamSynchronize(g->stream));
+    int fl[4] = {0, 0, 0, 0};
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+        for (size_t c0 = 0; c0 < g->N; c0 += chunk) {
+            size_t n = std::min(chunk, g->N - c0);
+            HIPCHK(g, hipMemcpyAsync(dm, mat + c0 * L, n * L, hipMemcpyHostToDevice, g->stream));
+            HIPCHK(g, hipMemcpyAsync(dz, zpair + 2 * c0 * L, n * L * 4, hipMemcpyHostToDevice, g->stream));
+            HIPCHK(g, hipMemcpyAsync(dl, len + c0, n, hipMemcpyHostToDevice, g->stream));
+            hipLaunchKernelGGL(k_scatter_columns, dim3(blocks_for(n)), dim3(256), 0, g->stream, view(g), c0, n, L, dm, dz, dl, g->d_flags);
+            HIPCHK(g, hipGetLastError());
+            HIPCHK(g, hipStreamSynchronize(g->stream));
+        }
+        int rc = read_flags(g, fl); if (rc) return rc;
+        if (fl[3] <= g->lmax) break;
+        // gaps need intervals of their own: provision the planes they take and convert again
+        rc = grow_planes(g, ((fl[3] - g->lmax + 15) / 16) * 16); if (rc) return rc;
     }
     (void)hipFree(dm); (void)hipFree(dz); (void)hipFree(dl);
-    int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
+    if (fl[1]) return fail(g, CG_ERR_UNSUPPORTED, "upload: a layer starts below the top of the layer under it");
+    if (fl[3] > g->lmax) return fail(g, CG_ERR_UNSUPPORTED, "upload: a column needs %d intervals (layers + gaps), more than 256", fl[3]);
     g->has_gaps = fl[2] != 0;
     g->len_bound = 255;            // refreshed lazily when it matters
     return CG_OK;
@@ -747,11 +851,9 @@ int cg_snapshot_save(cg_grid* g, int slot) {
     if (slot < 0) return fail(g, CG_ERR_ARG, "bad snapshot slot %d", slot);
     cg_snapshot_drop(g, slot);
     Snapshot s; size_t S = g->N * (size_t)g->lmax;
-    HIPCHK(g, hipMalloc(&s.len, g->N)); HIPCHK(g, hipMalloc(&s.mat, S)); HIPCHK(g, hipMalloc(&s.z0, 2 * S)); HIPCHK(g, hipMalloc(&s.z1, 2 * S));
+    HIPCHK(g, hipMalloc(&s.len, std::max<size_t>(g->N, 4))); HIPCHK(g, hipMalloc(&s.rec, std::max<size_t>(4 * S, 4)));
     HIPCHK(g, hipMemcpyAsync(s.len, g->len, g->N, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(s.mat, g->mat, S, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(s.z0, g->z0, 2 * S, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(s.z1, g->z1, 2 * S, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(s.rec, g->rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
     s.lmax = g->lmax; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps;
     g->snaps[slot] = s;
     return CG_OK;
@@ -766,9 +868,7 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     if (s.lmax != g->lmax) { HIPCHK(g, hipStreamSynchronize(g->stream)); int rc = alloc_planes(g, s.lmax); if (rc) return rc; }
     size_t S = g->N * (size_t)g->lmax;
     HIPCHK(g, hipMemcpyAsync(g->len, s.len, g->N, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(g->mat, s.mat, S, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(g->z0, s.z0, 2 * S, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(g->z1, s.z1, 2 * S, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(g->rec, s.rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
     g->len_bound = s.len_bound; g->has_gaps = s.has_gaps;
     return CG_OK;
 }
@@ -778,7 +878,7 @@ int cg_snapshot_drop(cg_grid* g, int slot) {
     auto it = g->snaps.find(slot);
     if (it == g->snaps.end()) return CG_OK;
     HIPCHK(g, hipStreamSynchronize(g->stream));
-    (void)hipFree(it->second.len); (void)hipFree(it->second.mat); (void)hipFree(it->second.z0); (void)hipFree(it->second.z1);
+    (void)hipFree(it->second.len); (void)hipFree(it->second.rec);
     g->snaps.erase(it);
     return CG_OK;
 }
@@ -804,7 +904,7 @@ int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count, void
     for (int s = 0; s < count; s++) {
         size_t col0 = axis == 0 ? (size_t)index[s] * g->ny : (size_t)index[s];
         size_t stride = axis == 0 ? 1 : (size_t)g->ny;
-        hipLaunchKernelGGL(k_gather_columns, dim3(blocks_for(line * L)), dim3(256), 0, g->stream, view(g), col0, stride, line, L,
+        hipLaunchKernelGGL(k_gather_columns, dim3(blocks_for(line)), dim3(256), 0, g->stream, view(g), col0, stride, line, L,
                            g->sl_mat + s * line * L, g->sl_zp + 2 * s * line * L, g->sl_len + s * line);
     }
     HIPCHK(g, hipGetLastError());
