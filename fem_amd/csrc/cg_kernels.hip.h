@@ -225,7 +225,7 @@ __device__ __forceinline__ int first_open_len(unsigned open, u8x4 ln) {
 }
 
 // top plane of a group, loaded ahead of time for the length of its first open column
-struct Pre4 { int l; u32x4 top; };
+struct Pre4 { int l; bool have_below; u32x4 top, below; };   // below: plane l-2, loaded too when have_below
 
 // _depoAtTop_ on the open columns of a group: column j grows by dz[j] (> 0).
 template <bool STATS>
@@ -296,7 +296,8 @@ __device__ __forceinline__ void etch_group4(const GridView& g, size_t c0, unsign
         rem &= ~active;
         double r[4] = {dz[0], dz[1], dz[2], dz[3]};
         u32x4 tv = (u32x4)(0);
-        if (l > 0) tv = (first && pre.l == l) ? pre.top : ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0);
+        const bool use_pre = first && pre.l == l;
+        if (l > 0) tv = use_pre ? pre.top : ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0);
         first = false;
         for (int cur = l; active && cur > 0; cur--) {
             // which active columns does this layer concern at all?
@@ -304,7 +305,8 @@ __device__ __forceinline__ void etch_group4(const GridView& g, size_t c0, unsign
 #pragma unroll
             for (int j = 0; j < 4; j++) if (((active >> j) & 1) && r[j] > CG_EPS && (isAll || rec_mat(tv[j]) == matId)) hit |= 1u << j;
             if (!hit) break;
-            const u32x4 bv = cur > 1 ? ld_rec4(g.rec + (size_t)(cur - 2) * g.N + c0) : (u32x4)(0);
+            u32x4 bv = (u32x4)(0);
+            if (cur > 1) bv = (use_pre && pre.have_below && cur == l) ? pre.below : ld_rec4(g.rec + (size_t)(cur - 2) * g.N + c0);
             u32x4 nv = tv;
             unsigned next = 0;
 #pragma unroll
@@ -353,7 +355,14 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
     const size_t tile_groups = (size_t)256 * U;
     const size_t ntiles = (ngroups + tile_groups - 1) / tile_groups;
     const double dz[4] = {t, t, t, t};
-    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Workgroup b always runs on the same XCD (b mod 8 in practice) and a fixed stride would hand it
+    // the same column range of every row; a masked step whose open area covers some column ranges
+    // only would then load the XCDs unevenly.  Rotating the assignment by one tile per sweep
+    // spreads every column range over all XCDs.
+    const size_t nsweeps = (ntiles + gridDim.x - 1) / gridDim.x;
+    for (size_t sweep = 0; sweep < nsweeps; sweep++) {
+        const size_t tile = sweep * gridDim.x + (blockIdx.x + sweep) % gridDim.x;
+        if (tile >= ntiles) continue;
         const size_t gbase = tile * tile_groups + threadIdx.x;
         u8x4 ln[U]; unsigned open[U]; Pre4 pre[U];
 #pragma unroll
@@ -368,10 +377,14 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            pre[u].l = -1;
+            pre[u].l = -1; pre[u].have_below = false;
             if (!open[u]) continue;
             const int l = first_open_len(open[u], ln[u]);
-            if (l > 0) { pre[u].l = l; pre[u].top = ld_rec4(g.rec + (size_t)(l - 1) * g.N + ((gbase + (size_t)u * 256) << 2)); }
+            if (l > 0) {
+                const size_t c0 = (gbase + (size_t)u * 256) << 2;
+                pre[u].l = l; pre[u].top = ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0);
+                if (ETCH && l > 1 && isAll) { pre[u].have_below = true; pre[u].below = ld_rec4(g.rec + (size_t)(l - 2) * g.N + c0); }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
     const int pitch = TJ + 2 * R;
     const int tile_rows = TI + 2 * R;
     const int tiles_j = (g.ny + TJ - 1) / TJ;
-    const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x % tiles_j;
+    const int tile_i = blockIdx.x / tiles_j, tile_j = (blockIdx.x % tiles_j + tile_i) % tiles_j;
     const int i_base = tile_i * TI, j_base = tile_j * TJ;
 
     // ---- stage heights (as float32 of q*zscale, cg1:465) with halo; flags fold into +inf
@@ -663,7 +676,9 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
     constexpr int Rp = G::Rp, PITCH = G::PITCH, ROWS = G::ROWS, W = G::W, GPR = G::GPR, TIS = G::TIS, GX = G::GX;
     __shared__ __align__(16) float s_h[ROWS * PITCH];
     const int tiles_j = (g.ny + TJS - 1) / TJS;
-    const int tile_i = blockIdx.x / tiles_j, tile_j = blockIdx.x - tile_i * tiles_j;
+    // rotate the column tile by the row tile so that one XCD (blockIdx mod 8) does not always get
+    // the same column range (see k_vertical_g4)
+    const int tile_i = blockIdx.x / tiles_j, tile_j = (blockIdx.x - tile_i * tiles_j + tile_i) % tiles_j;
     const int i_base = tile_i * TIS, j_base = tile_j * TJS;
     const float INF = __builtin_inff();
 
@@ -770,7 +785,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
             const u8x4 ln = ld_u8x4(g.len + c0);
             double dz[4] = {0, 0, 0, 0};
             unsigned open = 0;
-            Pre4 pre; pre.l = -1;
+            Pre4 pre; pre.l = -1; pre.have_below = false;
             if (STATS) loc[0] += __popc(act);
             if (!ETCH) {
 #pragma unroll
@@ -789,7 +804,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                 if (!isAll) {
                     // floor = bottom of the top run of matId (cg1:646-660)
                     u32x4 below = (u32x4)(0);
-                    if (uniform && l >= 2) below = ld_rec4(g.rec + (size_t)(l - 2) * g.N + c0);
+                    if (uniform && l >= 2) { below = ld_rec4(g.rec + (size_t)(l - 2) * g.N + c0); pre.have_below = true; pre.below = below; }
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
                         if (!((act >> c) & 1)) continue;
@@ -923,6 +938,196 @@ __global__ __launch_bounds__(256) void k_checksum(GridView g, unsigned long long
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, sum);
+}
+
+// ------------------------------------------------------------------------------------------
+// CMP (script_columngrid.js:747-859)
+// ------------------------------------------------------------------------------------------
+// out[0] = max z1q over every layer of material stopMat (0 when there is none), out[1] = 1 if any
+__global__ __launch_bounds__(256) void k_cmp_stopper_top(GridView g, int stopMat, unsigned* __restrict__ out) {
+    unsigned mq = 0, any = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const int l = min((int)g.len[c], g.lmax);
+        for (int k = 0; k < l; k++) {
+            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            if (!rec_hole(r) && rec_mat(r) == stopMat) { any = 1; mq = max(mq, rec_z1(r)); }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { mq = max(mq, (unsigned)__shfl_down(mq, o, 64)); any |= __shfl_down(any, o, 64); }
+    if ((threadIdx.x & 63) == 0 && any) { atomicMax(&out[0], mq); atomicOr(&out[1], 1u); }
+}
+
+// per-column truncation to limit = max(targetZ, z1 of the column's lowest stopper layer)
+__global__ __launch_bounds__(256) void k_cmp_apply(GridView g, double targetZ, int stopMat) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        int l = g.len[c];
+        if (l == 0) continue;
+        double stopZ = -__builtin_inf();
+        if (stopMat != 0)
+            for (int k = 0; k < l; k++) {
+                const uint32_t r = g.rec[(size_t)k * g.N + c];
+                if (!rec_hole(r) && rec_mat(r) == stopMat) { stopZ = (double)rec_z1(r) * g.zs; break; }      // cg1:801-806
+            }
+        const double limitZ = fmax(targetZ, stopZ);
+        const int l0 = l;
+        while (l > 0) {                                                                                      // cg1:813-834
+            const size_t b = (size_t)(l - 1) * g.N + c;
+            const uint32_t r = g.rec[b];
+            if (rec_hole(r)) { g.rec[b] = 0; l--; continue; }          // a gap uncovered by the removal above it
+            const uint32_t below = l > 1 ? g.rec[(size_t)(l - 2) * g.N + c] : 0;
+            const double z1 = (double)rec_z1(r) * g.zs, z0 = (double)rec_z1(below) * g.zs;
+            if (z1 <= limitZ + CG_EPS) break;
+            if (z0 < limitZ - CG_EPS) { g.rec[b] = rec_with_z1(r, quantz(limitZ, g.zs, g.inv_zs)); break; }
+            g.rec[b] = 0; l--;
+        }
+        if (l > 0) {                                                                                         // cg1:840-853
+            const size_t b = (size_t)(l - 1) * g.N + c;
+            const uint32_t r = g.rec[b];
+            const uint32_t below = l > 1 ? g.rec[(size_t)(l - 2) * g.N + c] : 0;
+            if (rec_z1(r) <= rec_z1(below)) {
+                g.rec[b] = 0; l--;
+                if (l > 0 && rec_hole(g.rec[(size_t)(l - 1) * g.N + c])) { g.rec[(size_t)(l - 1) * g.N + c] = 0; l--; }
+            }
+        }
+        if (l != l0) g.len[c] = (uint8_t)l;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// strip_connected (script_columngrid.js:867 - script_columngrid2.js:1) and identify_cavity
+// (script_columngrid2.js:9-83)
+// ------------------------------------------------------------------------------------------
+// Nodes are the layers of material matId; a node is a seed when it is exposed to air, and the
+// marked set is the closure of the seeds under "4-neighbour column, same material, z ranges
+// overlap".  The mark lives in the record's flag byte.  All height tests are done on the
+// quantised integers: the reference's eps (1e-9 nm) is far below one step, so
+// a < b - eps on de-quantised values is a < b on the integers.
+constexpr uint32_t REC_MARK = 2u << 24;
+
+__device__ __forceinline__ unsigned z0_of(const GridView& g, size_t c, int k) { return k > 0 ? rec_z1(g.rec[(size_t)(k - 1) * g.N + c]) : 0u; }
+
+// isExposed (cg1:882-905) for layer [z0q, z1q] of column (i, j)
+__device__ __forceinline__ bool layer_exposed(const GridView& g, int i, int j, unsigned z0q, unsigned z1q, unsigned topq) {
+    if (z0q == 0) return false;                       // resting on the floor: not exposed
+    if (z1q == topq) return true;                     // top of its column
+    const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const int ni = i + di[d], nj = j + dj[d];
+        if (ni < 0 || ni >= g.nx || nj < 0 || nj >= g.ny) return false;      // the domain edge ends the scan (cg1:896)
+        const size_t n = (size_t)ni * g.ny + nj;
+        const int nl = g.len[n];
+        if (nl == 0) return true;
+        if (rec_z1(g.rec[(size_t)(nl - 1) * g.N + n]) < z1q) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_strip_seed(GridView g, int matId) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const int l = g.len[c];
+        if (l == 0) continue;
+        const int i = (int)(c / g.ny), j = (int)(c - (size_t)i * g.ny);
+        const unsigned topq = rec_z1(g.rec[(size_t)(l - 1) * g.N + c]);
+        unsigned prev = 0;
+        for (int k = 0; k < l; k++) {
+            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            if (!rec_hole(r) && rec_mat(r) == matId && layer_exposed(g, i, j, prev, rec_z1(r), topq))
+                g.rec[(size_t)k * g.N + c] = r | REC_MARK;
+            prev = rec_z1(r);
+        }
+    }
+}
+
+// one relaxation sweep: an unmarked node next to an overlapping marked node becomes marked
+__global__ __launch_bounds__(256) void k_strip_flood(GridView g, int matId, int* __restrict__ changed) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    int any = 0;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const int l = g.len[c];
+        if (l == 0) continue;
+        const int i = (int)(c / g.ny), j = (int)(c - (size_t)i * g.ny);
+        unsigned prev = 0;
+        for (int k = 0; k < l; k++) {
+            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            const unsigned a0 = prev, a1 = rec_z1(r);
+            prev = a1;
+            if (rec_hole(r) || (r & REC_MARK) || rec_mat(r) != matId) continue;
+            bool hit = false;
+            const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
+#pragma unroll
+            for (int d = 0; d < 4 && !hit; d++) {
+                const int ni = i + di[d], nj = j + dj[d];
+                if (ni < 0 || ni >= g.nx || nj < 0 || nj >= g.ny) continue;
+                const size_t n = (size_t)ni * g.ny + nj;
+                const int nl = g.len[n];
+                unsigned b0 = 0;
+                for (int kk = 0; kk < nl; kk++) {
+                    const uint32_t rb = g.rec[(size_t)kk * g.N + n];
+                    const unsigned b1 = rec_z1(rb);
+                    if ((rb & REC_MARK) && !rec_hole(rb) && rec_mat(rb) == matId && a0 < b1 && b0 < a1) { hit = true; break; }   // cg1:879
+                    b0 = b1;
+                    if (b0 >= a1) break;              // everything above starts at or over our top
+                }
+            }
+            if (hit) { g.rec[(size_t)k * g.N + c] = r | REC_MARK; any = 1; }
+        }
+    }
+    if (any) *changed = 1;
+}
+
+// removal + compaction (cg1:970-999): marked layers go; one in the middle of a column leaves a
+// gap interval (adjacent gaps merge, a gap on top goes too).  flags[2] = a gap remains somewhere,
+// flags[1] = a cavity layer (material 2) remains somewhere.
+__global__ __launch_bounds__(256) void k_strip_compact(GridView g, int* __restrict__ flags) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    int gap = 0, cav = 0;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const int l = g.len[c];
+        int w = 0;
+        bool dirty = false;
+        for (int k = 0; k < l; k++) {
+            uint32_t r = g.rec[(size_t)k * g.N + c];
+            if (r & REC_MARK) { r = rec_z1(r) | REC_HOLE; dirty = true; }
+            if (rec_hole(r) && w > 0 && rec_hole(g.rec[(size_t)(w - 1) * g.N + c])) { w--; dirty = true; }   // merge with the gap below
+            if (dirty || w != k) g.rec[(size_t)w * g.N + c] = r;
+            w++;
+        }
+        while (w > 0 && rec_hole(g.rec[(size_t)(w - 1) * g.N + c])) { w--; dirty = true; }                    // no gap on top
+        if (dirty) {
+            for (int k = w; k < l; k++) g.rec[(size_t)k * g.N + c] = 0;
+            g.len[c] = (uint8_t)w;
+        }
+        for (int k = 0; k < w; k++) {
+            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            if (rec_hole(r)) gap = 1; else if (rec_mat(r) == 2) cav = 1;
+        }
+    }
+    if (gap) flags[2] = 1;
+    if (cav) flags[1] = 1;
+}
+
+// identify_cavity step 1 (cg2:23-71): every gap becomes a cavity layer (material 2) and every
+// column lower than the highest one gets a cavity layer up to that height.  The host has made
+// sure that a plane is free above every column.
+__global__ __launch_bounds__(256) void k_cavity_fill(GridView g, unsigned hmax_q) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const int l = g.len[c];
+        if (l == 0) continue;
+        for (int k = 0; k < l; k++) {
+            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            if (rec_hole(r)) g.rec[(size_t)k * g.N + c] = rec_make(rec_z1(r), 2);
+        }
+        const unsigned topq = rec_z1(g.rec[(size_t)(l - 1) * g.N + c]);
+        if (hmax_q > topq && l < g.lmax) {
+            g.rec[(size_t)l * g.N + c] = rec_make(hmax_q, 2);
+            g.len[c] = (uint8_t)(l + 1);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

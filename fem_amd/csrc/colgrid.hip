@@ -54,7 +54,7 @@ struct ConfKernel {
 
 struct Snapshot {
     uint8_t* len = nullptr; uint32_t* rec = nullptr;
-    int lmax = 0; int len_bound = 0; bool has_gaps = false;
+    int lmax = 0; int len_bound = 0; bool has_gaps = false, has_cavity = false;
 };
 
 struct Pending {
@@ -85,6 +85,7 @@ struct cg_grid {
     // invariants tracked on the host
     int len_bound = 0;          // upper bound of max(len); INT32_MAX = unknown
     bool has_gaps = false;      // some column may have a vertical gap between layers
+    bool has_cavity = false;    // some column may hold a cavity layer (material 2)
     // small device words: flags[0] overflow, [1] any etchable, [2] gap seen; red[0..1] reductions
     int* d_flags = nullptr; unsigned* d_red = nullptr; unsigned long long* d_sum = nullptr;
     unsigned long long* d_stats = nullptr; bool stats_on = false; uint64_t stats_host[CG_NSTAT] = {0};
@@ -188,9 +189,9 @@ int zero_planes(cg_grid* g, bool all = true) {
     const int planes = all ? g->lmax : std::min(g->lmax, std::max(0, g->len_bound));
     size_t S = g->N * (size_t)planes;
     HIPCHK(g, hipMemsetAsync(g->len, 0, g->N, g->stream));
-    if (S == 0) { g->len_bound = 0; g->has_gaps = false; return CG_OK; }
+    if (S == 0) { g->len_bound = 0; g->has_gaps = false; g->has_cavity = false; return CG_OK; }
     HIPCHK(g, hipMemsetAsync(g->rec, 0, 4 * S, g->stream));
-    g->len_bound = 0; g->has_gaps = false;
+    g->len_bound = 0; g->has_gaps = false; g->has_cavity = false;
     return CG_OK;
 }
 
@@ -436,7 +437,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
 
 template <bool ETCH>
 static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
-    const int U = vu_setting();
+    const int U = getenv("CG_VU") ? vu_setting() : (ETCH ? 1 : 2);     // etch needs the registers for itself
     const dim3 grid(blocks_for(g->N / 4 / U)), blk(256);
 #define LV(S, UU) hipLaunchKernelGGL((k_vertical_g4<ETCH, S, UU>), grid, blk, 0, g->stream, view(g), mask, mat, t, g->d_flags, g->d_stats)
     if (g->stats_on) { if (U == 1) LV(true, 1); else if (U == 2) LV(true, 2); else LV(true, 4); }
@@ -744,7 +745,7 @@ int cg_stencil_finish(cg_grid* g) {
     }
     if (g->len_bound < 255) g->len_bound += 1;
     // identify_cavity (cg1:543) -- a no-op while no column has a vertical gap
-    if (g->has_gaps) return cg_identify_cavity(g);
+    if (g->has_gaps || g->has_cavity) return cg_identify_cavity(g);
     return CG_OK;
 }
 
@@ -763,22 +764,79 @@ int cg_etch_general(cg_grid* g, int mask_id, int mat, double thickness, double c
 }
 
 int cg_cmp(cg_grid* g, double depth, int stop_mat) {
-    NEED(g); (void)depth; (void)stop_mat;
-    return fail(g, CG_ERR_UNSUPPORTED, "cmp is not built yet");
+    NEED(g);
+    if (!(depth > 0)) return CG_OK;                                        // cg1:748
+    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "cmp on a slab of a decomposed domain is not built yet");
+    if (stop_mat < 0 || stop_mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", stop_mat);
+    g->pend.active = false;
+    unsigned qtop = 0;
+    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    unsigned st[2] = {0, 0};
+    if (stop_mat != 0) {
+        ProfScope ps(g, CG_K_OTHER);
+        HIPCHK(g, hipMemsetAsync(g->d_red + 2, 0, 2 * sizeof(unsigned), g->stream));
+        hipLaunchKernelGGL(k_cmp_stopper_top, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), stop_mat, g->d_red + 2);
+        HIPCHK(g, hipGetLastError());
+        HIPCHK(g, hipMemcpyAsync(st, g->d_red + 2, sizeof st, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+    }
+    const double zTop = (double)qtop * g->zscale;                          // cg1:755-781
+    const double targetZ = (stop_mat == 0 || !st[1]) ? zTop - depth : std::max(zTop - depth, (double)st[0] * g->zscale);
+    {
+        ProfScope ps(g, CG_K_OTHER);
+        hipLaunchKernelGGL(k_cmp_apply, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), targetZ, stop_mat);
+        HIPCHK(g, hipGetLastError());
+    }
+    return cg_identify_cavity(g);                                          // cg1:858
 }
 
 int cg_strip_connected(cg_grid* g, int mat) {
-    NEED(g); (void)mat;
-    return fail(g, CG_ERR_UNSUPPORTED, "strip_connected is not built yet");
+    NEED(g);
+    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "strip_connected on a slab of a decomposed domain is not built yet");
+    if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
+    g->pend.active = false;
+    ProfScope ps(g, CG_K_OTHER);
+    const dim3 grid(blocks_for(g->N)), blk(256);
+    hipLaunchKernelGGL(k_strip_seed, grid, blk, 0, g->stream, view(g), mat);
+    HIPCHK(g, hipGetLastError());
+    // relax to the fixpoint; the flag is read back once per batch of sweeps
+    for (int round = 0;; round++) {
+        if (round > 1000000) return fail(g, CG_ERR_STATE, "strip_connected did not converge");
+        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
+        for (int sweep = 0; sweep < 4; sweep++) hipLaunchKernelGGL(k_strip_flood, grid, blk, 0, g->stream, view(g), mat, g->d_flags);
+        HIPCHK(g, hipGetLastError());
+        int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
+        if (!fl[0]) break;
+    }
+    HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+    hipLaunchKernelGGL(k_strip_compact, grid, blk, 0, g->stream, view(g), g->d_flags);
+    HIPCHK(g, hipGetLastError());
+    int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
+    g->has_gaps = fl[2] != 0;
+    g->has_cavity = fl[1] != 0;
+    return CG_OK;
 }
 
 int cg_identify_cavity(cg_grid* g) {
     NEED(g);
-    // With no vertical gap anywhere every inserted cavity piece is a column-top piece, hence
-    // exposed, hence stripped again (script_columngrid2.js:60-67, script_columngrid.js:891):
-    // the grid is left exactly as it was.
-    if (!g->has_gaps) return CG_OK;
-    return fail(g, CG_ERR_UNSUPPORTED, "identify_cavity on a grid with vertical gaps is not built yet");
+    // With no vertical gap and no cavity layer anywhere, every inserted cavity piece is a
+    // column-top piece, hence exposed, hence stripped again (script_columngrid2.js:60-67,
+    // script_columngrid.js:891), and nothing else of material 2 exists that the flood could
+    // reach: the grid is left exactly as it was.
+    if (!g->has_gaps && !g->has_cavity) return CG_OK;
+    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "identify_cavity with gaps on a slab of a decomposed domain is not built yet");
+    g->pend.active = false;
+    unsigned qtop = 0;
+    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    if (g->len_bound >= g->lmax) { rc = grow_planes(g); if (rc) return rc; }       // room for the piece above every column
+    const unsigned hmax_q = qtop > 0 ? qtop : (unsigned)js_round(1.0 / g->zscale) & 0xffffu;        // maxHeight() is 1 for a flat-zero grid (cg2:103)
+    {
+        ProfScope ps(g, CG_K_OTHER);
+        hipLaunchKernelGGL(k_cavity_fill, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), hmax_q);
+        HIPCHK(g, hipGetLastError());
+    }
+    if (g->len_bound < 255) g->len_bound += 1;
+    return cg_strip_connected(g, CG_MAT_CAVITY);                                    // cg2:79
 }
 
 int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q) {
@@ -842,6 +900,7 @@ int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8
     if (fl[1]) return fail(g, CG_ERR_UNSUPPORTED, "upload: a layer starts below the top of the layer under it");
     if (fl[3] > g->lmax) return fail(g, CG_ERR_UNSUPPORTED, "upload: a column needs %d intervals (layers + gaps), more than 256", fl[3]);
     g->has_gaps = fl[2] != 0;
+    g->has_cavity = true;          // not inspected: assume the upload may contain cavity layers
     g->len_bound = 255;            // refreshed lazily when it matters
     return CG_OK;
 }
@@ -854,7 +913,7 @@ int cg_snapshot_save(cg_grid* g, int slot) {
     HIPCHK(g, hipMalloc(&s.len, std::max<size_t>(g->N, 4))); HIPCHK(g, hipMalloc(&s.rec, std::max<size_t>(4 * S, 4)));
     HIPCHK(g, hipMemcpyAsync(s.len, g->len, g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(s.rec, g->rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
-    s.lmax = g->lmax; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps;
+    s.lmax = g->lmax; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps; s.has_cavity = g->has_cavity;
     g->snaps[slot] = s;
     return CG_OK;
 }
@@ -869,7 +928,7 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     size_t S = g->N * (size_t)g->lmax;
     HIPCHK(g, hipMemcpyAsync(g->len, s.len, g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->rec, s.rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
-    g->len_bound = s.len_bound; g->has_gaps = s.has_gaps;
+    g->len_bound = s.len_bound; g->has_gaps = s.has_gaps; g->has_cavity = s.has_cavity;
     return CG_OK;
 }
 

@@ -158,6 +158,54 @@ def test_random_flow_vs_oracle(nx, ny, seed):
     g.close()
 
 
+@pytest.mark.parametrize("nx,ny,seed", [(160, 224, 11), (301, 128, 12)])
+def test_random_flow_with_strip_cmp_cavity_vs_oracle(nx, ny, seed):
+    """Flows that create buried gaps and enclosed cavities: strip_connected, identify_cavity (through
+    conformal deposits and cmp) and cmp with and without a stopper, against the oracle step by step."""
+    fem = _engine()
+    rng = _lcg(seed)
+    L = 2 * max(nx, ny)
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    masks = []
+    for _ in range(3):
+        red = fem.reduce_mask(_random_mask_data(rng, L, 10))
+        masks.append((g.mask_from_shapes(red), o.mask_raster(red)))
+    steps = [("d", None, 3, 20, 0), ("d", None, 4, 8, 0), ("d", None, 5, 12, 0), ("e", 0, 255, 25, 0),
+             ("s", None, 4, 0, 0), ("c", None, 0, 0, 0), ("d", None, 6, 6, 1.0), ("e", 1, 255, 30, 0),
+             ("s", None, 4, 0, 0), ("d", None, 7, 5, 1.0), ("e", 2, 7, 4, 1.0), ("d", 1, 3, 9, 0.6),
+             ("p", None, 0, 4, 0), ("s", None, 6, 0, 0), ("d", None, 4, 7, 1.0), ("p", None, 5, 30, 0),
+             ("e", None, 255, 6, 1.0), ("p", None, 3, 40, 0), ("s", None, 3, 0, 0), ("c", None, 0, 0, 0)]
+    for idx, (kind, mi, mat, t, S) in enumerate(steps):
+        gm, om = (None, None) if mi is None else masks[mi]
+        if kind == "d":
+            g.deposit_general(gm, mat, t, S); o.deposit_general(om, mat, t, S)
+        elif kind == "e":
+            g.etch_general(gm, mat, t, S); o.etch_general(om, mat, t, S)
+        elif kind == "s":
+            g.strip_connected(mat); o.strip_connected(mat)
+        elif kind == "c":
+            g.identify_cavity(); o.identify_cavity()
+        elif kind == "p":
+            g.cmp(t, mat); o.cmp(t, mat)
+        assert g.checksum() == o.checksum(), f"step {idx} {kind} mat={mat} t={t} S={S} mask={mi}"
+        assert g.maxHeight() == o.max_height()
+    ln, mat, zp = g.download()
+    oln, omat, ozp = o.arrays()
+    L0 = min(g.Lmax, o.Lmax)
+    np.testing.assert_array_equal(ln, oln)
+    np.testing.assert_array_equal(mat.reshape(-1, g.Lmax)[:, :L0], omat.reshape(-1, o.Lmax)[:, :L0])
+    np.testing.assert_array_equal(zp.reshape(-1, g.Lmax, 2)[:, :L0], ozp.reshape(-1, o.Lmax, 2)[:, :L0])
+    # upload of a state with gaps and cavities, then keep going on both sides
+    g2 = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    g2.upload(oln, omat, ozp, o.Lmax)
+    assert g2.checksum() == o.checksum()
+    g2.etch_general(None, 255, 7, 0); o.etch_general(None, 255, 7, 0)
+    g2.deposit_general(None, 8, 5, 1.0); o.deposit_general(None, 8, 5, 1.0)
+    assert g2.checksum() == o.checksum()
+    g.close(); g2.close()
+
+
 def test_upload_download_roundtrip_and_slices():
     fem = _engine()
     case = load_case("stencil_small")
