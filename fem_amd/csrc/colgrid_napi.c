@@ -1,0 +1,343 @@
+/*
+ * colgrid_napi.c -- Node.js N-API glue over the C ABI of libcolgrid (include/colgrid.h).
+ *
+ * Plain C N-API (node_api.h); one JavaScript function per C entry point, same argument
+ * order.  A grid handle is a JavaScript external whose finalizer calls cg_destroy.  Typed
+ * arrays passed in are only read during the call (the library never keeps host pointers);
+ * arrays handed back are freshly allocated ArrayBuffers owned by JavaScript.  A non-zero
+ * status becomes a thrown Error carrying cg_last_error.
+ *
+ * The JavaScript classes with the reference's ColumnGrid / ProcessRuntime call surface
+ * (fem_amd/js/columngrid.js, runtime.js) are written against this module only.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/colgrid.h"
+
+#define NAPI_OK(env, call)                                                        \
+    do {                                                                          \
+        if ((call) != napi_ok) {                                                  \
+            napi_throw_error((env), NULL, "N-API call failed: " #call);          \
+            return NULL;                                                          \
+        }                                                                         \
+    } while (0)
+
+#define MAXARGS 8
+#define ARGS(env, info, n)                                                        \
+    size_t argc = MAXARGS; napi_value argv[MAXARGS];                              \
+    NAPI_OK(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));           \
+    if (argc < (size_t)(n)) { napi_throw_type_error(env, NULL, "too few arguments"); return NULL; }
+
+static napi_value throw_cg(napi_env env, cg_grid* g, int rc) {
+    char buf[600];
+    const char* msg = cg_last_error(g);
+    snprintf(buf, sizeof buf, "libcolgrid error %d: %s", rc, msg ? msg : "");
+    napi_throw_error(env, NULL, buf);
+    return NULL;
+}
+
+static void finalize_grid(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    cg_grid** box = (cg_grid**)data;
+    if (box) { if (*box) cg_destroy(*box); free(box); }
+}
+
+static cg_grid* grid_of(napi_env env, napi_value v) {
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !*(cg_grid**)p) {
+        napi_throw_type_error(env, NULL, "not a live colgrid handle");
+        return NULL;
+    }
+    return *(cg_grid**)p;
+}
+
+static int get_double(napi_env env, napi_value v, double* out) {
+    napi_value num;
+    if (napi_coerce_to_number(env, v, &num) != napi_ok || napi_get_value_double(env, num, out) != napi_ok) {
+        napi_throw_type_error(env, NULL, "number expected"); return 0;
+    }
+    return 1;
+}
+static int get_int(napi_env env, napi_value v, int32_t* out) {
+    double d; if (!get_double(env, v, &d)) return 0;
+    *out = (int32_t)d; return 1;
+}
+
+static napi_value wrap_grid(napi_env env, cg_grid* g) {
+    cg_grid** box = (cg_grid**)malloc(sizeof *box);
+    *box = g;
+    napi_value ext;
+    if (napi_create_external(env, box, finalize_grid, NULL, &ext) != napi_ok) { cg_destroy(g); free(box); napi_throw_error(env, NULL, "external"); return NULL; }
+    return ext;
+}
+
+static napi_value undefined(napi_env env) { napi_value u; napi_get_undefined(env, &u); return u; }
+
+static napi_value new_typed(napi_env env, napi_typedarray_type type, size_t count, size_t elem, void** data) {
+    napi_value ab, ta;
+    if (napi_create_arraybuffer(env, count * elem, data, &ab) != napi_ok) { napi_throw_error(env, NULL, "arraybuffer"); return NULL; }
+    if (napi_create_typedarray(env, type, count, ab, 0, &ta) != napi_ok) { napi_throw_error(env, NULL, "typedarray"); return NULL; }
+    return ta;
+}
+
+static int typed_in(napi_env env, napi_value v, napi_typedarray_type want, void** data, size_t* count) {
+    napi_typedarray_type t; napi_value ab; size_t off;
+    bool is = false;
+    if (napi_is_typedarray(env, v, &is) != napi_ok || !is ||
+        napi_get_typedarray_info(env, v, &t, count, data, &ab, &off) != napi_ok || t != want) {
+        napi_throw_type_error(env, NULL, "typed array of the wrong kind"); return 0;
+    }
+    return 1;
+}
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+static napi_value js_create(napi_env env, napi_callback_info info) {          /* cg_create */
+    ARGS(env, info, 6);
+    double lx, ly, dx, dy, zs; int32_t lmax;
+    if (!get_double(env, argv[0], &lx) || !get_double(env, argv[1], &ly) || !get_double(env, argv[2], &dx) ||
+        !get_double(env, argv[3], &dy) || !get_int(env, argv[4], &lmax) || !get_double(env, argv[5], &zs)) return NULL;
+    cg_grid* g = NULL;
+    int rc = cg_create(lx, ly, dx, dy, lmax, zs, &g);
+    if (rc) return throw_cg(env, NULL, rc);
+    return wrap_grid(env, g);
+}
+
+static napi_value js_create_slab(napi_env env, napi_callback_info info) {     /* cg_create_slab */
+    ARGS(env, info, 8);
+    int32_t nxg, ny, i0, nxl, lmax; double dx, dy, zs;
+    if (!get_int(env, argv[0], &nxg) || !get_int(env, argv[1], &ny) || !get_int(env, argv[2], &i0) || !get_int(env, argv[3], &nxl) ||
+        !get_double(env, argv[4], &dx) || !get_double(env, argv[5], &dy) || !get_int(env, argv[6], &lmax) || !get_double(env, argv[7], &zs)) return NULL;
+    cg_grid* g = NULL;
+    int rc = cg_create_slab(nxg, ny, i0, nxl, dx, dy, lmax, zs, &g);
+    if (rc) return throw_cg(env, NULL, rc);
+    return wrap_grid(env, g);
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info) {         /* cg_destroy */
+    ARGS(env, info, 1);
+    void* p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p && *(cg_grid**)p) { cg_destroy(*(cg_grid**)p); *(cg_grid**)p = NULL; }
+    return undefined(env);
+}
+
+#define SIMPLE0(NAME, CALL)                                                   \
+    static napi_value NAME(napi_env env, napi_callback_info info) {           \
+        ARGS(env, info, 1);                                                   \
+        cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;              \
+        int rc = CALL(g); if (rc) return throw_cg(env, g, rc);                \
+        return undefined(env);                                                \
+    }
+SIMPLE0(js_clear, cg_clear)
+SIMPLE0(js_identify_cavity, cg_identify_cavity)
+SIMPLE0(js_sync, cg_sync)
+
+static napi_value js_reset(napi_env env, napi_callback_info info) {           /* cg_reset */
+    ARGS(env, info, 2);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t lmax; if (!get_int(env, argv[1], &lmax)) return NULL;
+    int rc = cg_reset(g, lmax); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+
+static napi_value js_info(napi_env env, napi_callback_info info) {            /* cg_get_info */
+    ARGS(env, info, 1);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    cg_info inf; int rc = cg_get_info(g, &inf); if (rc) return throw_cg(env, g, rc);
+    napi_value o, v; NAPI_OK(env, napi_create_object(env, &o));
+#define SETI(name, val) do { napi_create_int32(env, (val), &v); napi_set_named_property(env, o, name, v); } while (0)
+#define SETD(name, val) do { napi_create_double(env, (val), &v); napi_set_named_property(env, o, name, v); } while (0)
+    SETI("nx", inf.nx); SETI("ny", inf.ny); SETI("nxGlobal", inf.nx_global); SETI("i0", inf.i0); SETI("lmax", inf.lmax); SETI("device", inf.device);
+    SETD("dx", inf.dx); SETD("dy", inf.dy); SETD("zscale", inf.zscale); SETD("offsetX", inf.offset_x); SETD("offsetY", inf.offset_y);
+    SETD("lxEff", inf.lx_eff); SETD("lyEff", inf.ly_eff);
+    return o;
+}
+
+/* ---- masks ------------------------------------------------------------------------------- */
+static napi_value js_mask_from_raster(napi_env env, napi_callback_info info) {   /* cg_mask_from_raster */
+    ARGS(env, info, 2);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    void* data; size_t n; if (!typed_in(env, argv[1], napi_uint8_array, &data, &n)) return NULL;
+    int id = -1; int rc = cg_mask_from_raster(g, (const uint8_t*)data, n, &id); if (rc) return throw_cg(env, g, rc);
+    napi_value v; napi_create_int32(env, id, &v); return v;
+}
+
+static napi_value js_mask_from_shapes(napi_env env, napi_callback_info info) {   /* cg_mask_from_shapes */
+    ARGS(env, info, 4);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    void *sh, *pts; size_t nb, np; int32_t nshapes;
+    if (!typed_in(env, argv[1], napi_uint8_array, &sh, &nb) || !get_int(env, argv[2], &nshapes) ||
+        !typed_in(env, argv[3], napi_float64_array, &pts, &np)) return NULL;
+    if (nshapes < 0 || (size_t)nshapes * sizeof(cg_shape) > nb) { napi_throw_range_error(env, NULL, "shape buffer too small"); return NULL; }
+    /* the ArrayBuffer may not be 8-byte aligned for the doubles inside cg_shape: copy */
+    cg_shape* copy = (cg_shape*)malloc((nshapes > 0 ? nshapes : 1) * sizeof(cg_shape));
+    if (nshapes > 0) memcpy(copy, sh, (size_t)nshapes * sizeof(cg_shape));
+    int id = -1; int rc = cg_mask_from_shapes(g, copy, nshapes, (const double*)pts, (int)(np / 2), &id);
+    free(copy);
+    if (rc) return throw_cg(env, g, rc);
+    napi_value v; napi_create_int32(env, id, &v); return v;
+}
+
+static napi_value js_mask_download(napi_env env, napi_callback_info info) {      /* cg_mask_download */
+    ARGS(env, info, 2);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t id; if (!get_int(env, argv[1], &id)) return NULL;
+    cg_info inf; cg_get_info(g, &inf);
+    size_t n = (size_t)inf.nx * inf.ny; void* data;
+    napi_value ta = new_typed(env, napi_uint8_array, n, 1, &data); if (!ta) return NULL;
+    int rc = cg_mask_download(g, id, (uint8_t*)data, n); if (rc) return throw_cg(env, g, rc);
+    return ta;
+}
+
+static napi_value js_mask_destroy(napi_env env, napi_callback_info info) {       /* cg_mask_destroy */
+    ARGS(env, info, 2);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t id; if (!get_int(env, argv[1], &id)) return NULL;
+    int rc = cg_mask_destroy(g, id); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+
+/* ---- steps --------------------------------------------------------------------------------- */
+static napi_value step4(napi_env env, napi_callback_info info, int (*fn)(cg_grid*, int, int, double, double)) {
+    ARGS(env, info, 5);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t mask, mat; double t, S;
+    if (!get_int(env, argv[1], &mask) || !get_int(env, argv[2], &mat) || !get_double(env, argv[3], &t) || !get_double(env, argv[4], &S)) return NULL;
+    int rc = fn(g, mask, mat, t, S); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+static napi_value js_deposit_general(napi_env env, napi_callback_info info) { return step4(env, info, cg_deposit_general); }
+static napi_value js_etch_general(napi_env env, napi_callback_info info) { return step4(env, info, cg_etch_general); }
+
+static napi_value js_cmp(napi_env env, napi_callback_info info) {                /* cg_cmp */
+    ARGS(env, info, 3);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    double depth; int32_t stop; if (!get_double(env, argv[1], &depth) || !get_int(env, argv[2], &stop)) return NULL;
+    int rc = cg_cmp(g, depth, stop); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+
+static napi_value js_strip_connected(napi_env env, napi_callback_info info) {    /* cg_strip_connected */
+    ARGS(env, info, 2);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t mat; if (!get_int(env, argv[1], &mat)) return NULL;
+    int rc = cg_strip_connected(g, mat); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+
+static napi_value js_max_height(napi_env env, napi_callback_info info) {         /* cg_max_height */
+    ARGS(env, info, 1);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    double z; int rc = cg_max_height(g, &z, NULL); if (rc) return throw_cg(env, g, rc);
+    napi_value v; napi_create_double(env, z, &v); return v;
+}
+
+/* ---- data exchange ------------------------------------------------------------------------- */
+static napi_value js_download(napi_env env, napi_callback_info info) {           /* cg_download */
+    ARGS(env, info, 1);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    cg_info inf; cg_get_info(g, &inf);
+    size_t n = (size_t)inf.nx * inf.ny, L = (size_t)inf.lmax;
+    void *m, *z, *l;
+    napi_value tm = new_typed(env, napi_uint8_array, n * L, 1, &m); if (!tm) return NULL;
+    napi_value tz = new_typed(env, napi_uint16_array, 2 * n * L, 2, &z); if (!tz) return NULL;
+    napi_value tl = new_typed(env, napi_uint8_array, n, 1, &l); if (!tl) return NULL;
+    int rc = cg_download(g, (uint8_t*)m, (uint16_t*)z, (uint8_t*)l); if (rc) return throw_cg(env, g, rc);
+    napi_value o, v; NAPI_OK(env, napi_create_object(env, &o));
+    napi_set_named_property(env, o, "mat", tm); napi_set_named_property(env, o, "zpair", tz); napi_set_named_property(env, o, "len", tl);
+    napi_create_int32(env, inf.lmax, &v); napi_set_named_property(env, o, "lmax", v);
+    return o;
+}
+
+static napi_value js_upload(napi_env env, napi_callback_info info) {             /* cg_upload */
+    ARGS(env, info, 5);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    void *m, *z, *l; size_t nm, nz, nl; int32_t lmax;
+    if (!typed_in(env, argv[1], napi_uint8_array, &m, &nm) || !typed_in(env, argv[2], napi_uint16_array, &z, &nz) ||
+        !typed_in(env, argv[3], napi_uint8_array, &l, &nl) || !get_int(env, argv[4], &lmax)) return NULL;
+    cg_info inf; cg_get_info(g, &inf);
+    size_t n = (size_t)inf.nx * inf.ny;
+    if (lmax < 1 || nl != n || nm != n * (size_t)lmax || nz != 2 * n * (size_t)lmax) { napi_throw_range_error(env, NULL, "array sizes do not match the grid"); return NULL; }
+    int rc = cg_upload(g, (const uint8_t*)m, (const uint16_t*)z, (const uint8_t*)l, lmax); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+
+static napi_value snap(napi_env env, napi_callback_info info, int (*fn)(cg_grid*, int)) {
+    ARGS(env, info, 2);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t slot; if (!get_int(env, argv[1], &slot)) return NULL;
+    int rc = fn(g, slot); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+static napi_value js_snapshot_save(napi_env env, napi_callback_info info) { return snap(env, info, cg_snapshot_save); }
+static napi_value js_snapshot_load(napi_env env, napi_callback_info info) { return snap(env, info, cg_snapshot_load); }
+static napi_value js_snapshot_drop(napi_env env, napi_callback_info info) { return snap(env, info, cg_snapshot_drop); }
+
+static napi_value js_slices(napi_env env, napi_callback_info info) {             /* cg_slices */
+    ARGS(env, info, 3);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t axis; void* idx; size_t cnt;
+    if (!get_int(env, argv[1], &axis) || !typed_in(env, argv[2], napi_int32_array, &idx, &cnt)) return NULL;
+    cg_info inf; cg_get_info(g, &inf);
+    size_t line = axis == 0 ? (size_t)inf.ny : (size_t)inf.nx, n = line * cnt, L = (size_t)inf.lmax;
+    void *m, *z, *l;
+    napi_value tm = new_typed(env, napi_uint8_array, n * L, 1, &m); if (!tm) return NULL;
+    napi_value tz = new_typed(env, napi_uint16_array, 2 * n * L, 2, &z); if (!tz) return NULL;
+    napi_value tl = new_typed(env, napi_uint8_array, n, 1, &l); if (!tl) return NULL;
+    int rc = cg_slices(g, axis, (const int32_t*)idx, (int)cnt, (uint8_t*)m, (uint16_t*)z, (uint8_t*)l); if (rc) return throw_cg(env, g, rc);
+    napi_value o, v; NAPI_OK(env, napi_create_object(env, &o));
+    napi_set_named_property(env, o, "mat", tm); napi_set_named_property(env, o, "zpair", tz); napi_set_named_property(env, o, "len", tl);
+    napi_create_int32(env, inf.lmax, &v); napi_set_named_property(env, o, "lmax", v);
+    napi_create_int32(env, (int32_t)line, &v); napi_set_named_property(env, o, "line", v);
+    return o;
+}
+
+static napi_value js_index_from_pos(napi_env env, napi_callback_info info) {     /* cg_index_from_pos */
+    ARGS(env, info, 3);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t axis; double pos; if (!get_int(env, argv[1], &axis) || !get_double(env, argv[2], &pos)) return NULL;
+    int32_t out = 0; int rc = cg_index_from_pos(g, axis, pos, &out); if (rc) return throw_cg(env, g, rc);
+    napi_value v; napi_create_int32(env, out, &v); return v;
+}
+
+static napi_value js_checksum(napi_env env, napi_callback_info info) {           /* cg_checksum -> 16 hex digits */
+    ARGS(env, info, 1);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    uint64_t s = 0; int rc = cg_checksum(g, &s); if (rc) return throw_cg(env, g, rc);
+    char buf[32]; snprintf(buf, sizeof buf, "%016llx", (unsigned long long)s);
+    napi_value v; napi_create_string_utf8(env, buf, NAPI_AUTO_LENGTH, &v); return v;
+}
+
+static napi_value js_version(napi_env env, napi_callback_info info) {            /* cg_version */
+    (void)info; napi_value v; napi_create_string_utf8(env, cg_version(), NAPI_AUTO_LENGTH, &v); return v;
+}
+
+static napi_value js_shape_bytes(napi_env env, napi_callback_info info) {        /* sizeof(cg_shape), for the packing code */
+    (void)info; napi_value v; napi_create_int32(env, (int32_t)sizeof(cg_shape), &v); return v;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+    static const struct { const char* name; napi_callback fn; } fns[] = {
+        {"create", js_create}, {"createSlab", js_create_slab}, {"destroy", js_destroy}, {"reset", js_reset}, {"clear", js_clear},
+        {"info", js_info}, {"sync", js_sync},
+        {"maskFromRaster", js_mask_from_raster}, {"maskFromShapes", js_mask_from_shapes}, {"maskDownload", js_mask_download},
+        {"maskDestroy", js_mask_destroy},
+        {"depositGeneral", js_deposit_general}, {"etchGeneral", js_etch_general}, {"cmp", js_cmp},
+        {"stripConnected", js_strip_connected}, {"identifyCavity", js_identify_cavity}, {"maxHeight", js_max_height},
+        {"download", js_download}, {"upload", js_upload},
+        {"snapshotSave", js_snapshot_save}, {"snapshotLoad", js_snapshot_load}, {"snapshotDrop", js_snapshot_drop},
+        {"slices", js_slices}, {"indexFromPos", js_index_from_pos}, {"checksum", js_checksum}, {"version", js_version},
+        {"shapeBytes", js_shape_bytes},
+    };
+    for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
+        napi_value f;
+        if (napi_create_function(env, fns[k].name, NAPI_AUTO_LENGTH, fns[k].fn, NULL, &f) != napi_ok) return NULL;
+        if (napi_set_named_property(env, exports, fns[k].name, f) != napi_ok) return NULL;
+    }
+    return exports;
+}
+
+NAPI_MODULE(colgrid_napi, init)

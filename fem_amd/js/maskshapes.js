@@ -11,7 +11,7 @@
 'use strict';
 
 const SHAPE_RECT = 0, SHAPE_CIRCLE = 1, SHAPE_ELLIPSE = 2, SHAPE_POLYGON = 3, SHAPE_NEVER = 4;
-const SHAPE_BYTES = 120;          // sizeof(cg_shape): 6 x int32 + 12 x double
+const SHAPE_BYTES = 104;          // sizeof(cg_shape): 6 x int32 + 10 x double
 
 // -> { open: true }                         no objects list: every column is open (rt:56)
 //    { shapes: [[...15 numbers]], pts: [] } otherwise; invisible objects are dropped (rt:62)

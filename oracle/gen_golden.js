@@ -273,3 +273,25 @@ for (const NX of [256, 64]) {
   fs.writeFileSync(path.join(OUT, 'quantize.json'), JSON.stringify({ quant: out, dequant: deq,
     nextpow2: [0, 1, 2, 3, 16, 31, 32, 33, 48].map(n => [n, g._nextPowerOf2(n)]) }));
 }
+
+// 12. the runtime's replay / caching policy (rt:183-299): the sequence of grid calls the
+//     reference runtime makes during a scripted editing session, recorded with a fake grid
+{
+  const { makeFakeGridClass, session } = require('../tests/js/fake_grid.js');
+  const log = [];
+  const S = session();
+  ref.window.prj.gridRenderer = { updateFromGrid() { log.push(['render']); } };
+  ref.window.prj.ColumnGrid = makeFakeGridClass(log);
+  ref.window.prj.processFlow = { materialColor: S.materialColor };
+  ref.window.prj.maskmanager = { maskList: S.maskList };
+  const rt = new ref.ProcessRuntime({ LX: 200, LY: 200, dx: 2, dy: 2 });
+  const marks = [];
+  for (const [snapshot, opts] of S.events) {
+    marks.push(log.length);
+    let err = null;
+    try { rt._build(snapshot, opts); } catch (e) { err = e.constructor.name; }
+    if (err) log.push(['throw', err]);
+  }
+  fs.writeFileSync(path.join(OUT, 'runtime_trace.json'), JSON.stringify({ log, marks }));
+  console.log('runtime_trace', log.length, 'calls');
+}
