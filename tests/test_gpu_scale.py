@@ -1,0 +1,164 @@
+"""Benchmark flows at scale: oracle equality where the oracle finishes in seconds, and
+size-independent properties at the full 16384 x 16384 benchmark size."""
+import numpy as np
+import pytest
+
+from oracle import OracleGrid
+
+pytestmark = pytest.mark.gpu
+
+
+def _masks(fem, flows, g, o, specs, names, n):
+    import torch
+    gm, om = {}, {}
+    for name in names:
+        spec = specs[name]
+        if spec["kind"] == "shapes":
+            red = fem.reduce_mask(spec["data"])
+            gm[name] = g.mask_from_shapes(red)
+            if o is not None:
+                om[name] = o.mask_raster(red)
+        else:
+            r = flows.raster_torch(spec, n, n, 0, torch.device("cuda", 0))
+            torch.cuda.synchronize()
+            gm[name] = g.mask_from_device_raster(r.data_ptr(), r.numel())
+            g.sync()
+            if o is not None:
+                om[name] = flows.raster_numpy(spec, n, n)
+                # closed form == the reference predicate on the expanded shape list (small sizes only)
+                if n <= 512:
+                    np.testing.assert_array_equal(om[name], o.mask_raster(fem.reduce_mask(flows.shapes_of(spec, 2 * n, 2 * n))))
+                np.testing.assert_array_equal(gm[name].download(), om[name])
+    return gm, om
+
+
+@pytest.mark.parametrize("flow_name,n", [("c2", 512), ("c3", 512), ("c4", 1024), ("c5", 384)])
+def test_benchmark_flows_vs_oracle(flow_name, n):
+    import fem_amd as fem
+    from fem_amd import flows
+    flow = flows.FLOWS[flow_name]()
+    specs = flows.mask_specs(2.0 * n)
+    g = fem.ColumnGrid(2.0 * n, 2.0 * n, 2.0, 2.0)
+    o = OracleGrid(2.0 * n, 2.0 * n, 2.0, 2.0)
+    gm, om = _masks(fem, flows, g, o, specs, sorted({s["mask"] for s in flow if s["mask"]}), n)
+    g.stats_enable(True)
+    for k, s in enumerate(flow):
+        flows.apply_step(g, s, gm)
+        flows.apply_step(o, s, om)
+        assert g.checksum() == o.checksum(), f"{flow_name} step {k} {s}"
+        gs, os_ = g.stats(), o.stats()
+        assert gs[2:6] == os_[2:6], f"{flow_name} step {k} column counts {gs} vs {os_}"
+        if flow_name == "c5":     # C5 extracts cross-sections after every step
+            idx = [min(n - 1, 37 * q + 5) for q in range(8)]
+            ln, mat, zp = o.arrays(); L = o.Lmax
+            for axis in ("YZ", "XZ"):
+                sl, sm, sz = g.slices(axis, idx)
+                for q, i in enumerate(idx):
+                    ref_len = ln.reshape(n, n)[i] if axis == "YZ" else ln.reshape(n, n)[:, i]
+                    ref_mat = mat.reshape(n, n, L)[i] if axis == "YZ" else mat.reshape(n, n, L)[:, i]
+                    np.testing.assert_array_equal(sl[q], ref_len)
+                    np.testing.assert_array_equal(sm[q][:, :L], ref_mat[:, :g.Lmax])
+    assert g.Lmax == o.Lmax
+    ln, mat, zp = g.download()
+    oln, omat, ozp = o.arrays()
+    np.testing.assert_array_equal(ln, oln); np.testing.assert_array_equal(mat, omat); np.testing.assert_array_equal(zp, ozp)
+    g.close()
+
+
+def test_full_size_properties():
+    """16384 x 16384 (the benchmark size): no oracle, only properties that do not depend on size."""
+    import fem_amd as fem
+    from fem_amd import flows
+    n = 16384
+    specs = flows.mask_specs(2.0 * n)
+    g = fem.ColumnGrid(dx=2.0, dy=2.0, slab=(n, n, 0, n))
+    gm, _ = _masks(fem, flows, g, None, specs, ["M", "Mc", "Mr"], n)
+    g.deposit_general(None, 3, 30, 0)
+    c0 = g.checksum()
+    assert g.maxHeight() == 30.0
+    # deposit + equal etch of the same material is the identity (vertical and lateral)
+    g.deposit_general(None, 4, 20, 0); g.etch_general(None, 4, 20, 0)
+    assert g.checksum() == c0
+    g.deposit_general(None, 4, 6, 1.0); g.etch_general(None, 4, 6, 0)
+    assert g.checksum() == c0
+    # a masked etch followed by the etch of the complement equals the unmasked etch
+    g.snapshot_save(0)
+    g.etch_general(gm["M"], 3, 7.5, 0)
+    inv = g.mask_from_raster(1 - gm["M"].download())
+    g.etch_general(inv, 3, 7.5, 0)
+    c_split = g.checksum()
+    g.snapshot_load(0)
+    g.etch_general(None, 3, 7.5, 0)
+    assert g.checksum() == c_split and g.maxHeight() == 22.5
+    # translation symmetry: the periodic mask Mc has pitch 24 cells; a conformal step on a periodic
+    # state keeps row i and row i + 24*k identical away from the domain edges
+    g.snapshot_load(0)
+    g.etch_general(gm["Mc"], 3, 12, 0)
+    g.deposit_general(None, 5, 10, 1.0)
+    g.etch_general(None, 5, 6, 1.0)
+    sl, sm, sz = g.slices("YZ", [48, 48 + 24 * 100, 48 + 24 * 600])
+    np.testing.assert_array_equal(sl[0], sl[1]); np.testing.assert_array_equal(sz[0], sz[2]); np.testing.assert_array_equal(sm[0], sm[1])
+    # sum of slab checksums == whole grid (the checksum is a sum over columns keyed by global index)
+    g.close()
+
+
+def test_plane_growth_inside_a_conformal_step():
+    """Lmax 2 -> 18: the overflow re-run of vertical and conformal deposits against the oracle.
+
+    The flow stops before a column is exactly Lmax layers tall at the end of a conformal step: there the
+    reference's identify_cavity writes its top cavity piece past the column's slots into the next
+    column and leaves len = Lmax + 1 (script_columngrid2.js:60-69 has no bound check), after which its
+    state is corrupt.  The engine does not reproduce that."""
+    import fem_amd as fem
+    n = 96
+    g = fem.ColumnGrid(2.0 * n, 2.0 * n, 2.0, 2.0, 2)
+    o = OracleGrid(2.0 * n, 2.0 * n, 2.0, 2.0, lmax=2)
+    rng = np.random.RandomState(5)
+    m = (rng.rand(n * n) < 0.6).astype(np.uint8)
+    gmask = g.mask_from_raster(m)
+    steps = [("d", None, 3, 10, 0), ("d", gmask, 4, 5, 0), ("d", None, 5, 6, 1.0), ("d", gmask, 6, 4, 0.8), ("e", gmask, 255, 7, 1.0)]
+    steps += [("d", None if k % 2 else gmask, 3 + k % 5, 2 + k % 3, (k % 3) / 2) for k in range(12)]
+    for idx, (kind, mk, mat, t, S) in enumerate(steps):
+        om = None if mk is None else m
+        if kind == "d":
+            g.deposit_general(mk, mat, t, S); o.deposit_general(om, mat, t, S)
+        else:
+            g.etch_general(mk, mat, t, S); o.etch_general(om, mat, t, S)
+        assert g.Lmax == o.Lmax, f"step {idx}"
+        assert g.checksum() == o.checksum(), f"step {idx}"
+    ln, mat, zp = g.download(); oln, omat, ozp = o.arrays()
+    np.testing.assert_array_equal(ln, oln); np.testing.assert_array_equal(mat, omat); np.testing.assert_array_equal(zp, ozp)
+    g.close()
+
+
+def test_edge_cases():
+    import fem_amd as fem
+    # 1 x 1 grid, empty grid ops, zero / negative thickness, mask with no open column
+    g = fem.ColumnGrid(2, 2, 2, 2)
+    assert (g.NX, g.NY) == (1, 1)
+    assert g.maxHeight() == 1.0                       # empty grid: maxHeight() is 1 (script_columngrid2.js:103)
+    g.etch_general(None, 255, 5, 0); g.etch_general(None, 255, 5, 1.0)
+    g.deposit_general(None, 3, 0, 0); g.deposit_general(None, 3, -4, 1.0)
+    assert g.download()[0][0] == 0
+    g.deposit_general(None, 3, 6553.5, 0)
+    g.deposit_general(None, 3, 0.2, 0)               # Uint16 wrap: 65537 -> 1
+    o = OracleGrid(2, 2, 2, 2); o.deposit_general(None, 3, 6553.5, 0); o.deposit_general(None, 3, 0.2, 0)
+    assert g.checksum() == o.checksum()
+    g.close()
+    g = fem.ColumnGrid(14, 22, 2, 2)                 # 7 x 11: no vector path
+    o = OracleGrid(14, 22, 2, 2)
+    closed = g.mask_from_raster(np.zeros(77, np.uint8))
+    for args in [(None, 3, 10, 0), (closed, 4, 5, 0), (closed, 4, 5, 1.0), (None, 4, 3, 1.0)]:
+        g.deposit_general(*args); o.deposit_general(None if args[0] is None else np.zeros(77, np.uint8), *args[1:])
+    g.etch_general(closed, 255, 5, 1.0); o.etch_general(np.zeros(77, np.uint8), 255, 5, 1.0)
+    assert g.checksum() == o.checksum()
+    with pytest.raises(fem.ColGridError):
+        g.deposit_general(fem.Mask(g, 99), 3, 1, 0)  # unknown mask id
+    g.close()
+    with pytest.raises(fem.ColGridError):
+        fem.ColumnGrid(10, 10, 0, 2)                 # bad pitch
+    g = fem.ColumnGrid(20, 20, 2, 4)                 # dx != dy: vertical steps fine, lateral ones refused
+    g.deposit_general(None, 3, 10, 0)
+    with pytest.raises(fem.ColGridError):
+        g.deposit_general(None, 4, 10, 1.0)
+    g.close()
