@@ -158,8 +158,8 @@ def main():
             t = max(0.0, s["t"]); S = 0.0 if s["kind"] == "SUBSTR" else max(0.0, min(1.0, s["S"]))
             stencil = t * S >= 2.0
             if s["kind"] in ("SUBSTR", "DEPO"):
-                return "k_stencil_apply<deposit>" if stencil else "k_depo_vertical"
-            return "k_stencil_apply<etch>" if stencil else "k_etch_vertical"
+                return "k_stencil_sym<deposit>" if stencil else "k_vertical_g4<deposit>"
+            return "k_stencil_sym<etch>" if stencil else "k_vertical_g4<etch>"
         kbytes = {}
         for q in range(args.steps):
             idx = (k + q) % len(flow)

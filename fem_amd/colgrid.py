@@ -20,8 +20,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcolgrid.so")
 CG_MASK_NONE = -1
 CG_NSTAT = 8
 CG_NKIND = 12
-KERNEL_KINDS = ["k_depo_vertical", "k_etch_vertical", "k_snapshot_tops", "k_halo_pack/unpack",
-                "k_stencil_apply<deposit>", "k_stencil_apply<etch>", "k_mask_shapes", "clear(memset)",
+KERNEL_KINDS = ["k_vertical_g4<deposit>", "k_vertical_g4<etch>", "k_snapshot_tops_g4", "k_halo_pack/unpack",
+                "k_stencil_sym<deposit>", "k_stencil_sym<etch>", "k_mask_shapes", "clear(memset)",
                 "k_max_top", "other", "-", "-"]
 STENCIL_DEPOSIT, STENCIL_ETCH = 0, 1
 SHAPE_RECT, SHAPE_CIRCLE, SHAPE_ELLIPSE, SHAPE_POLYGON, SHAPE_NEVER = range(5)

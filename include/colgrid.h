@@ -235,12 +235,12 @@ int cg_step_stats(cg_grid* g, int enable, uint64_t stats[CG_NSTAT]);
  * pair of HIP events on the handle's stream (no host synchronisation at launch time).
  * A call synchronises the stream, returns the milliseconds and launch counts accumulated
  * per kernel kind since the previous call, clears them, and sets the enabled state. */
-#define CG_K_DEPO_VERTICAL   0   /* k_depo_vertical                                            */
-#define CG_K_ETCH_VERTICAL   1   /* k_etch_vertical                                            */
+#define CG_K_DEPO_VERTICAL   0   /* k_vertical_g4<deposit> (k_vertical_1 when N % 4 != 0)       */
+#define CG_K_ETCH_VERTICAL   1   /* k_vertical_g4<etch>                                          */
 #define CG_K_SNAPSHOT        2   /* k_snapshot_tops                                            */
 #define CG_K_HALO            3   /* k_halo_pack / k_halo_unpack                                */
-#define CG_K_STENCIL_DEPOSIT 4   /* k_stencil_apply<deposit>                                   */
-#define CG_K_STENCIL_ETCH    5   /* k_stencil_apply<etch>                                      */
+#define CG_K_STENCIL_DEPOSIT 4   /* k_stencil_sym<deposit> (k_stencil_apply for radius > 8)     */
+#define CG_K_STENCIL_ETCH    5   /* k_stencil_sym<etch>                                          */
 #define CG_K_MASK            6   /* k_mask_shapes                                              */
 #define CG_K_CLEAR           7   /* memsets of cg_reset / cg_clear                             */
 #define CG_K_REDUCE          8   /* k_max_top                                                  */
