@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
             if (l > 0) {
                 const size_t c0 = (gbase + (size_t)u * 256) << 2;
                 pre[u].l = l; pre[u].top = ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0);
-                if (ETCH && l > 1 && isAll) { pre[u].have_below = true; pre[u].below = ld_rec4(g.rec + (size_t)(l - 2) * g.N + c0); }
+                if (ETCH && l > 1) { pre[u].have_below = true; pre[u].below = ld_rec4(g.rec + (size_t)(l - 2) * g.N + c0); }
             }
         }
 #pragma unroll
