@@ -50,7 +50,11 @@ typedef struct og_grid {
     og_kernel *kc[40]; int nkc;
     /* statistics of the last stencil/vertical step (for the byte model) */
     uint64_t stats[CG_NSTAT];
+    /* sliderCache of the reference (cg1:34): filled by deposit_ALD / etch_wet */
+    struct og_slider *slider;
 } og_grid;
+
+void og_slider_reset(og_grid *g);
 
 /* ---- JS number helpers ---------------------------------------------------------------- */
 static double js_round(double x) {           /* Math.round */
@@ -102,6 +106,7 @@ og_grid *og_create(double lx, double ly, double dx, double dy, int lmax_init, do
 
 void og_destroy(og_grid *g) {
     if (!g) return;
+    og_slider_reset(g);
     for (int i = 0; i < g->nkc; i++) {
         free(g->kc[i]->row_off); free(g->kc[i]->dv); free(g->kc[i]->add); free(g->kc[i]);
     }
@@ -858,3 +863,6 @@ int og_index_from_pos(const og_grid *g, int axis, double pos) {
     if (r < 0) r = 0; if (r > n - 1) r = n - 1;
     return (int)r;
 }
+
+/* ---- deposit_ALD and etch_wet (cg2:111 - cg3:308) --------------------------------------- */
+#include "colgrid_oracle_ald_wet.inc"

@@ -83,9 +83,17 @@ function runCase(name, domain, masks, steps, opts = {}) {
       case 'strip_connected': g.strip_connected(s.mat); break;
       case 'identify_cavity': g.identify_cavity(); break;
       case 'reset': g.createNewGrid(); break;
+      case 'etch_wet': g.etch_wet(s.mat, s.t, s.dt === undefined ? { isCache: !!s.isCache } : { isCache: !!s.isCache, dt: s.dt }); break;
+      case 'deposit_ALD': g.deposit_ALD(s.mat, s.t, s.dt === undefined ? { isCache: !!s.isCache } : { isCache: !!s.isCache, dt: s.dt }); break;
+      case 'slider_reset': g.sliderCache = {}; break;
       default: throw new Error('unknown op ' + s.op);
     }
     const rec = Object.assign({}, s, { fnv: H.gridHash(g), lmax: g.Lmax, max_height: g.maxHeight() });
+    if (g.sliderCache && (g.sliderCache.aldCache || g.sliderCache.wetetchCache)) {
+      const a = g.sliderCache.aldCache, w = g.sliderCache.wetetchCache;
+      rec.slider = { ald_keys: a ? Array.from(a.gridWithCavity.keys()) : [], seeds: a && a.exposedSegments ? a.exposedSegments.length : 0,
+        wet_keys: w ? Array.from(w.grid.keys()) : [], wet_R: w ? w.R : 0 };
+    }
     if (s.dump || idx === steps.length - 1) {
       if (!opts.noDump) { rec.dump_index = out.dumps.length; out.dumps.push({ step: idx, lmax: g.Lmax }); bins.push(dumpGrid(g)); }
     }
@@ -200,6 +208,33 @@ const etc = (mask, mat, t, S = 0, dump = false) => ({ op: 'etch_general', mask, 
     dep('all', 6, 6, 1.0, true), etc('pit', 255, 30, 0), { op: 'strip_connected', mat: 4, dump: true },
     dep(null, 7, 5, 1.0, true), { op: 'cmp', t: 4, mat: 0, dump: true }, { op: 'cmp', t: 30, mat: 5, dump: true },
     { op: 'cmp', t: 30, mat: 3, dump: true }, etc('all', 255, 3, 1.0, true),
+  ]);
+}
+
+// 7b. wet etch and ALD (cg2:111 - cg3:308): undercut, pinch-off cavities, the slider caches,
+//     and thin gaps that put several runs of air into one 32-bin word of the ALD bitsets
+{
+  const wet = (mat, t, o = {}) => Object.assign({ op: 'etch_wet', mat, t, dump: true }, o);
+  const ald = (mat, t, o = {}) => Object.assign({ op: 'deposit_ALD', mat, t, dump: true }, o);
+  const masks = {
+    trench: { objects: [rect(0, 0, 200, 200), rect(24, 8, 14, 30, neg), rect(46, 20, 6, 20, neg)] },
+    pit: { objects: [rect(0, 0, 200, 200), rect(8, 30, 8, 8, neg)] },
+  };
+  runCase('wet_ald_small', D(64, 48), masks, [
+    dep('all', 3, 20, 0), dep('all', 4, 8, 0), dep('all', 5, 12, 0), etc('trench', 255, 25, 0, true),
+    wet(4, 3), ald(6, 3), wet(255, 2.5), ald(7, 5), etc('pit', 255, 60, 0), wet(3, 5, { dt: 1.5 }), ald(4, 4.5, { dt: 1 }),
+    { op: 'cmp', t: 6, mat: 0, dump: true }, wet(7, 2),
+  ]);
+  runCase('wet_ald_cache', D(48, 40), masks, [
+    dep('all', 3, 20, 0), dep('all', 4, 8, 0), dep('all', 5, 12, 0), etc('trench', 255, 25, 0, true),
+    wet(4, 6), wet(4, 4, { isCache: true }), wet(4, 7.5, { isCache: true }), wet(4, 1, { isCache: true }),
+    { op: 'slider_reset' }, ald(6, 6), ald(6, 3, { isCache: true }), ald(6, 7, { isCache: true }), ald(6, 1.5, { isCache: true }),
+    { op: 'slider_reset' }, wet(255, 3.3, { isCache: true }), ald(7, 2.2, { isCache: true }),
+  ]);
+  runCase('wet_ald_thin', D(40, 32), masks, [
+    dep('all', 3, 20, 0), dep('all', 4, 1, 0), dep('all', 5, 0.5, 0), dep('all', 4, 0.7, 0), dep('all', 5, 1.3, 0), dep('all', 4, 0.4, 0),
+    dep('all', 5, 9, 0), etc('trench', 255, 20, 0, true), wet(4, 4), ald(6, 1.1, { dt: 0.5 }), ald(7, 2.9), wet(5, 1.2, { dt: 0.4 }),
+    ald(3, 0.3), wet(255, 0.7),
   ]);
 }
 

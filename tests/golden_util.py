@@ -8,7 +8,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 STEP_CASES = ["vertical_small", "stencil_small", "stencil_odd", "anchor_256", "masks_small",
-              "growth_small", "cavity_small", "kcache_small"]
+              "growth_small", "cavity_small", "kcache_small", "wet_ald_small", "wet_ald_cache", "wet_ald_thin"]
 
 
 def load_case(name):
@@ -60,6 +60,12 @@ def run_steps(grid, case, mask_of, on_step=None):
             grid.identify_cavity()
         elif op == "reset":
             grid.reset()
+        elif op == "etch_wet":
+            grid.etch_wet(s["mat"], s["t"], dt=s.get("dt"), isCache=s.get("isCache", False))
+        elif op == "deposit_ALD":
+            grid.deposit_ALD(s["mat"], s["t"], dt=s.get("dt"), isCache=s.get("isCache", False))
+        elif op == "slider_reset":
+            grid.slider_reset()
         else:
             raise ValueError(op)
         if on_step:

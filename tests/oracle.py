@@ -33,8 +33,8 @@ def shapes_from_reduced(reduced):
 
 
 def _lib():
-    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
-            os.path.join(ROOT, "oracle", "colgrid_oracle.c")):
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("colgrid_oracle.c", "colgrid_oracle_ald_wet.inc")]
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     L = C.CDLL(_SO)
     vp, i, d = C.c_void_p, C.c_int, C.c_double
@@ -65,6 +65,14 @@ def _lib():
     L.og_kernel_info.argtypes = [vp, d, d, C.POINTER(i), C.POINTER(i)]
     L.og_kernel_taps.argtypes = [vp, d, d, vp, vp, vp]
     L.og_index_from_pos.argtypes = [vp, i, d]
+    L.og_etch_wet.argtypes = [vp, i, d, d, i]
+    L.og_etch_wet_step.argtypes = [vp, i, i, i]
+    L.og_deposit_ald.argtypes = [vp, i, d, d, i]
+    L.og_slider_reset.argtypes = [vp]
+    L.og_slider_ald_entries.argtypes = [vp]
+    L.og_slider_wet_entries.argtypes = [vp]
+    L.og_slider_seed_count.restype = C.c_size_t; L.og_slider_seed_count.argtypes = [vp]
+    L.og_ald_taps.argtypes = [vp, d, vp, vp, vp]
     return L
 
 
@@ -144,6 +152,34 @@ class OracleGrid:
 
     def reset(self, lmax=0):
         self.L.og_reset(self.h, lmax)
+
+    def etch_wet(self, mat, t, dt=None, isCache=False):
+        rc = self.L.og_etch_wet(self.h, mat, t, float("nan") if dt is None else dt, int(bool(isCache)))
+        if rc:
+            raise RuntimeError("the reference throws here (etch_wet rc=%d)" % rc)
+
+    def etch_wet_step(self, mat, dtq, diagonal):
+        rc = self.L.og_etch_wet_step(self.h, mat, dtq, int(bool(diagonal)))
+        if rc:
+            raise RuntimeError("the reference throws here (etch_wet step rc=%d)" % rc)
+
+    def deposit_ALD(self, mat, t, dt=None, isCache=False):
+        rc = self.L.og_deposit_ald(self.h, mat, t, float("nan") if dt is None else dt, int(bool(isCache)))
+        if rc:
+            raise RuntimeError("the reference loses its state here (deposit_ALD rc=%d)" % rc)
+
+    def slider_reset(self):
+        self.L.og_slider_reset(self.h)
+
+    def slider_sizes(self):
+        return (self.L.og_slider_ald_entries(self.h), self.L.og_slider_wet_entries(self.h),
+                self.L.og_slider_seed_count(self.h))
+
+    def ald_taps(self, t):
+        n = self.L.og_ald_taps(self.h, t, None, None, None)
+        du = np.zeros(n, np.int32); dv = np.zeros(n, np.int32); add = np.zeros(n, np.float64)
+        self.L.og_ald_taps(self.h, t, _ptr(du), _ptr(dv), _ptr(add))
+        return du, dv, add
 
     def max_height(self):
         return self.L.og_max_height(self.h)

@@ -38,6 +38,9 @@ def test_steps_match_reference(name):
         assert g.fnv() == s["fnv"], f"{name} step {idx} {s['op']}"
         assert g.Lmax == s["lmax"]
         assert g.max_height() == s["max_height"]
+        if "slider" in s:
+            na, nw, nseed = g.slider_sizes()
+            assert (na, nw, nseed) == (len(s["slider"]["ald_keys"]), len(s["slider"]["wet_keys"]), s["slider"]["seeds"])
         if "dump_index" in s:
             ln, mat, zp, lm = case["dump_arrays"][s["dump_index"]]
             oln, omat, ozp = g.arrays()
