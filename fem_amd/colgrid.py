@@ -71,6 +71,15 @@ ABI = {
     "cg_cmp": (_i, [_vp, _d, _i]),
     "cg_strip_connected": (_i, [_vp, _i]),
     "cg_identify_cavity": (_i, [_vp]),
+    "cg_etch_wet": (_i, [_vp, _i, _d, _d]),
+    "cg_etch_wet_step": (_i, [_vp, _i, _i, _i]),
+    "cg_deposit_ald": (_i, [_vp, _i, _d, _d]),
+    "cg_ald_collect_seeds": (_i, [_vp, _d, C.POINTER(C.c_uint64)]),
+    "cg_ald_seed_info": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_uint64)]),
+    "cg_ald_drop_seeds": (_i, [_vp]),
+    "cg_ald_increment": (_i, [_vp, _i, _d]),
+    "cg_ald_coat": (_i, [_vp, _i, _d]),
+    "cg_release_scratch": (_i, [_vp]),
     "cg_max_height": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_uint32)]),
     "cg_stencil_begin": (_i, [_vp, _i, _i, _i, _d, _d, _i, _i, C.POINTER(_i)]),
     "cg_halo_buffers": (_i, [_vp, _pp, _pp, _pp, _pp, C.POINTER(_sz)]),
@@ -233,6 +242,10 @@ class ColumnGrid:
         self.h = out
         self.nMaxCache = 10
         self._info = None
+        # sliderCache of the reference (script_columngrid.js:34): anchors of etch_wet / deposit_ALD
+        self.sliderCache = {}
+        self.keep_step_snapshots = True      # the reference stores one grid copy per increment
+        self._next_slot = 1 << 24
 
     # ---- plumbing
     def _chk(self, rc):
@@ -318,6 +331,115 @@ class ColumnGrid:
 
     def identify_cavity(self):
         self._chk(self.lib.cg_identify_cavity(self.h))
+
+    # ---- etch_wet / deposit_ALD with the reference's anchors (sliderCache)
+    @staticmethod
+    def _js_round(x):
+        r = math.floor(x)
+        return r + 1 if x - r >= 0.5 else r
+
+    def _drop_slots(self, slots):
+        for slot in slots:
+            self.snapshot_drop(slot)
+
+    def slider_reset(self):
+        """this.sliderCache = {} (script_columngrid.js:244, script_runtime.js:275)."""
+        wc = self.sliderCache.get("wetetchCache")
+        ac = self.sliderCache.get("aldCache")
+        if wc:
+            self._drop_slots(wc["grid"].values())
+        if ac:
+            self._drop_slots(ac["gridWithCavity"].values())
+            self._chk(self.lib.cg_ald_drop_seeds(self.h))
+        self.sliderCache = {}
+
+    def _anchor(self, table, T):
+        best = -1
+        for k in table:
+            if k <= T + 1e-9 and k > best:
+                best = k
+        return best if best >= 0 else None
+
+    def _save_anchor(self, table, key):
+        if not self.keep_step_snapshots:
+            return
+        if key not in table:
+            table[key] = self._next_slot
+            self._next_slot += 1
+        self.snapshot_save(table[key])
+
+    def etch_wet(self, matId, totalThk, dt=None, isCache=False):
+        """etch_wet(matId, totalThk, {dt, isCache}) (script_columngrid2.js:893 - script_columngrid3.js:308)."""
+        T = float(totalThk)
+        T = 0.0 if T != T else max(0.0, T)
+        if T <= 0:
+            return
+        inf = self.info()
+        zs = inf.zscale
+        base_dt = max(min(inf.dx, inf.dy) if dt is None else float(dt), 1e-6)
+        wc = self.sliderCache.setdefault("wetetchCache", {"grid": {}, "R": 0})
+        R, t = 0.0, 0.0
+        if isCache and wc["grid"]:
+            best = self._anchor(wc["grid"], T)
+            if best is not None:
+                self.snapshot_load(wc["grid"][best])
+                R = float(wc["R"]) or 0.0
+                t = best
+        try:
+            while t < T - 1e-9:
+                R += 0.7071067811865476
+                diag = False
+                if R > 1:
+                    R -= 1
+                    diag = True
+                dt_q = max(1, int(self._js_round(min(base_dt, T - t) / zs)))
+                self._chk(self.lib.cg_etch_wet_step(self.h, int(matId), dt_q, int(diag)))
+                t += dt_q * zs
+                self._save_anchor(wc["grid"], t)
+                wc["R"] = R
+            self.identify_cavity()
+        finally:
+            self.lib.cg_release_scratch(self.h)
+
+    def deposit_ALD(self, matId, totalThk, dt=None, isCache=False):
+        """deposit_ALD(matId, totalThk, {dt, isCache}) (script_columngrid2.js:111-868)."""
+        T = float(totalThk)
+        T = 0.0 if T != T else max(0.0, T)
+        if T <= 0:
+            return
+        inf = self.info()
+        step = max(max(inf.dx, inf.dy, min(inf.dx, inf.dy)) if dt is None else float(dt), 1e-3)
+        ac = self.sliderCache.setdefault("aldCache", {"exposedSegments": None, "gridWithCavity": {}})
+        if not (isCache and ac["exposedSegments"] is not None):
+            n = C.c_uint64()
+            self._chk(self.lib.cg_ald_collect_seeds(self.h, T, C.byref(n)))
+            ac["exposedSegments"] = n.value
+        t_anchor = 0.0
+        if isCache and ac["gridWithCavity"]:
+            best = self._anchor(ac["gridWithCavity"], T)
+            if best is not None:
+                self.snapshot_load(ac["gridWithCavity"][best])
+                t_anchor = best
+        try:
+            t = t_anchor + step
+            while t < T - 1e-9:
+                self._chk(self.lib.cg_ald_increment(self.h, int(matId), t))
+                self._save_anchor(ac["gridWithCavity"], t)
+                t += step
+            self._chk(self.lib.cg_ald_coat(self.h, int(matId), T))
+            self._save_anchor(ac["gridWithCavity"], T)
+            self.identify_cavity()
+        finally:
+            self.lib.cg_release_scratch(self.h)
+
+    def etch_wet_step(self, matId, dt_q, diagonal):
+        self._chk(self.lib.cg_etch_wet_step(self.h, int(matId), int(dt_q), int(bool(diagonal))))
+
+    def slider_sizes(self):
+        """(ALD anchors, wet-etch anchors, seeds held) -- what the reference keeps in sliderCache."""
+        ac = self.sliderCache.get("aldCache"); wc = self.sliderCache.get("wetetchCache")
+        return (len(ac["gridWithCavity"]) if ac else 0, len(wc["grid"]) if wc else 0,
+                (ac["exposedSegments"] or 0) if ac else 0)
 
     def maxHeight(self):
         z = C.c_double()

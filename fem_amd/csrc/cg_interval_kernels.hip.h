@@ -1,0 +1,507 @@
+// Device code of libcolgrid, part 2: the two incremental process models of the reference,
+//   etch_wet     script_columngrid2.js:893 - script_columngrid3.js:308   (integer intervals)
+//   deposit_ALD  script_columngrid2.js:111-868                           (bitsets of height bins)
+//
+// Both read the OLD state of neighbouring columns while a column is rewritten, and both can
+// make a column longer or shorter anywhere in its stack, so every kernel here reads one set of
+// planes and writes another (the host swaps them afterwards).  One thread owns one column.
+//
+// etch_wet works on the quantised integers, exactly like the reference.  deposit_ALD is stated
+// by the reference on 32-bit words of per-column bitsets, and two of its routines do not do
+// what their comments say:
+//   * markRangeQ (cg2:170-184) masks the last word of a range with (1 << (s1 + 1)) - 1, which
+//     JavaScript evaluates to 0 for s1 == 31: a range that ends on a word boundary loses its
+//     last word;
+//   * emitIntervals (cg2:197-324) shifts the word it scans but adds bit positions to the word's
+//     base only, so the second and later runs of ones inside one word come out displaced.
+// The results depend on both, so both are reproduced on the same words: each thread keeps its
+// bitsets in LDS (word-major, stride = block size), and the run scanner is the same state
+// machine.  Heights compare as integers: every height involved is q*zscale for an integer q,
+// and the reference's eps (1e-9 nm) is far below one step.
+#pragma once
+#include "cg_kernels.hip.h"
+
+namespace cgk {
+
+// ------------------------------------------------------------------------------------------
+// writing a column as a stream of (z0, z1, material) pieces in ascending order
+// ------------------------------------------------------------------------------------------
+struct ColWriter {
+    uint32_t* rec; size_t N, c; int lmax;
+    int w = 0; unsigned top = 0;
+    bool gap = false, cav = false, bad = false;
+    __device__ ColWriter(const GridView& d, size_t c_) : rec(d.rec), N(d.N), c(c_), lmax(d.lmax) {}
+    __device__ void put(unsigned q0, unsigned q1, int m) {
+        if (q0 > top) { if (w < lmax) rec[(size_t)w * N + c] = (q0 & 0xffffu) | REC_HOLE; w++; gap = true; }
+        else if (q0 < top) bad = true;                         // cannot be represented
+        if (w < lmax) rec[(size_t)w * N + c] = rec_make(q1, m);
+        w++; top = q1;
+        if (m == 2) cav = true;
+    }
+    __device__ void raw(uint32_t r) {                          // verbatim copy of an interval
+        if (w < lmax) rec[(size_t)w * N + c] = r;
+        w++;
+        if (rec_hole(r)) gap = true; else if (rec_mat(r) == 2) cav = true;
+    }
+    // flags[1] cavity layer seen, [2] gap seen, [3] largest column, [0] unrepresentable column
+    __device__ void finish(uint8_t* len, int* __restrict__ flags) {
+        const int old = len[c];
+        for (int k = min(w, lmax); k < old; k++) rec[(size_t)k * N + c] = 0;
+        len[c] = (uint8_t)min(min(w, lmax), 255);
+        if (gap) flags[2] = 1;
+        if (cav) flags[1] = 1;
+        if (bad || w > 255) flags[0] = 1;
+        if (w > flags[3]) atomicMax(&flags[3], w);
+    }
+};
+
+__device__ __forceinline__ void copy_column(const GridView& s, const GridView& d, size_t c, int* __restrict__ flags) {
+    ColWriter W(d, c);
+    const int l = s.len[c];
+    for (int k = 0; k < l; k++) W.raw(s.rec[(size_t)k * s.N + c]);
+    W.finish(d.len, flags);
+}
+
+// ------------------------------------------------------------------------------------------
+// etch_wet: one increment (stepOnce, script_columngrid3.js:250-268, without identify_cavity)
+// ------------------------------------------------------------------------------------------
+// Air runs of column n inside [0, Hq): everything that is not covered by a layer of material
+// >= 2 (cg3:12-36).  f(a, b) is called for each maximal run, bottom to top.
+template <class F>
+__device__ __forceinline__ void for_each_air_q(const GridView& g, size_t n, unsigned Hq, F&& f) {
+    const int l = g.len[n];
+    unsigned prev = 0; bool open = false; unsigned a = 0;
+    for (int k = 0; k < l; k++) {
+        const uint32_t r = g.rec[(size_t)k * g.N + n];
+        const unsigned z1 = rec_z1(r);
+        if (z1 <= prev) continue;                              // zero-thickness entries are not segments (cg2:983)
+        const bool occ = !rec_hole(r) && rec_mat(r) >= 2;
+        if (!occ) { if (!open) { open = true; a = prev; } }
+        else if (open) { f(a, prev); open = false; }
+        prev = z1;
+    }
+    if (!open) { open = true; a = prev; }
+    if (Hq > a) f(a, Hq);
+}
+
+// Removal intervals thrown at column (i, j) by the air of its neighbours (cg3:91-155).
+template <class F>
+__device__ __forceinline__ void for_each_lateral_cut(const GridView& g, int i, int j, unsigned Hq, int d, bool diag, F&& f) {
+    const int di4[4] = {1, -1, 0, 0}, dj4[4] = {0, 0, 1, -1};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int ni = i + di4[q], nj = j + dj4[q];
+        if (ni < 0 || nj < 0 || ni >= g.nx || nj >= g.ny) continue;
+        for_each_air_q(g, (size_t)ni * g.ny + nj, Hq, [&](unsigned a, unsigned b) {
+            const int q0 = max(0, (int)a - d), q1 = min((int)Hq, (int)b + d);
+            if (q1 > q0) f(q0, q1);
+        });
+    }
+    if (diag) {
+        const int di8[4] = {1, 1, -1, -1}, dj8[4] = {1, -1, 1, -1};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int ni = i + di8[q], nj = j + dj8[q];
+            if (ni < 0 || nj < 0 || ni >= g.nx || nj >= g.ny) continue;
+            for_each_air_q(g, (size_t)ni * g.ny + nj, Hq, [&](unsigned a, unsigned b) {
+                int q0 = (int)a + d, q1 = (int)b - d;
+                if (q1 <= q0) return;
+                q0 = max(q0, 0); q1 = min(q1, (int)Hq);
+                if (q1 > q0) f(q0, q1);
+            });
+        }
+    }
+}
+
+__device__ __forceinline__ bool wet_target(int matId, int m) { return matId == 255 ? m >= 3 : m == matId; }   // cg3:46-49
+
+struct WetOut {                                                // merge of touching pieces of one material (cg3:183-193)
+    ColWriter W; bool have = false; unsigned p0 = 0, p1 = 0; int pm = 0;
+    __device__ WetOut(const GridView& d, size_t c) : W(d, c) {}
+    __device__ void flush() { if (have) W.put(p0, p1, pm); have = false; }
+    __device__ void put(unsigned s0, unsigned s1, int m) {
+        if (have && s0 <= p1 && m == pm) { p1 = max(p1, s1); return; }
+        flush(); have = true; p0 = s0; p1 = s1; pm = m;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_wet_step(GridView s, GridView d, int matId, int dtQ, int dtQDiag, int diag, unsigned Hq,
+                                                  int* __restrict__ flags) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < s.N; c += stride) {
+        const int l = s.len[c];
+        const int i = (int)(c / s.ny), j = (int)(c - (size_t)i * s.ny);
+        // is there any removal interval for this column?  (cg3:166-167: none -> untouched)
+        bool any = false;
+        {                                                      // a target segment whose top or bottom faces air (cg3:52-87)
+            unsigned prev = 0, below_end = 0; bool seg_below = false; int below_m = 0;
+            for (int k = 0; k < l; k++) {
+                const uint32_t r = s.rec[(size_t)k * s.N + c];
+                const unsigned q0 = prev, q1 = rec_z1(r);
+                if (q1 <= q0) continue;
+                prev = q1;
+                if (rec_hole(r)) continue;
+                const int m = rec_mat(r);
+                if (seg_below && below_end < q0 && (wet_target(matId, below_m) || wet_target(matId, m))) any = true;
+                seg_below = true; below_end = q1; below_m = m;
+            }
+            if (seg_below && wet_target(matId, below_m)) any = true;
+        }
+        if (!any) for_each_lateral_cut(s, i, j, Hq, dtQDiag, diag != 0, [&](int, int) { any = true; });
+        if (!any) { copy_column(s, d, c, flags); continue; }
+
+        WetOut out(d, c);
+        unsigned prev = 0;
+        bool seg_below = false; unsigned below_end = 0;        // the previous segment, if any
+        for (int k = 0; k < l; k++) {
+            const uint32_t r = s.rec[(size_t)k * s.N + c];
+            const unsigned q0 = prev, q1 = rec_z1(r);
+            if (q1 <= q0) continue;
+            prev = q1;
+            if (rec_hole(r)) continue;
+            const int m = rec_mat(r);
+            const bool gap_below = seg_below && below_end < q0;
+            seg_below = true; below_end = q1;
+            if (!wet_target(matId, m)) { out.put(q0, q1, m); continue; }
+            // the next segment above, if any: a gap in between (or nothing above) exposes the top
+            bool top_exposed = true;
+            {
+                unsigned p = q1;
+                for (int kk = k + 1; kk < l; kk++) {
+                    const uint32_t rr = s.rec[(size_t)kk * s.N + c];
+                    const unsigned z = rec_z1(rr);
+                    if (z <= p) continue;
+                    if (!rec_hole(rr)) { top_exposed = p > q1; break; }
+                    p = z;
+                }
+            }
+            const int vt0 = top_exposed ? max((int)q0, (int)q1 - dtQ) : 0, vt1 = top_exposed ? (int)q1 : 0;      // cg3:58-78
+            const int vb0 = gap_below ? (int)q0 : 0, vb1 = gap_below ? min((int)q1, (int)q0 + dtQ) : 0;          // cg3:79-84
+            int cur = (int)q0;
+            while (cur < (int)q1) {                            // [q0, q1) minus the union of the removal intervals
+                int cover = cur, nxt = (int)q1;
+                auto see = [&](int a, int b) {
+                    if (b <= a) return;
+                    if (a <= cur) { if (b > cover) cover = b; }
+                    else if (a < nxt) nxt = a;
+                };
+                see(vt0, vt1); see(vb0, vb1);
+                for_each_lateral_cut(s, i, j, Hq, dtQDiag, diag != 0, see);
+                if (cover > cur) { cur = cover; continue; }
+                out.put((unsigned)cur, (unsigned)nxt, m);
+                cur = nxt;
+            }
+        }
+        out.flush();
+        out.W.finish(d.len, flags);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// deposit_ALD
+// ------------------------------------------------------------------------------------------
+// One column's bitset in LDS: word w of the thread's column at base[w * stride].
+struct BitCol {
+    uint32_t* base; int stride; int wpc;
+    __device__ uint32_t get(int w) const { return base[(size_t)w * stride]; }
+    __device__ void set(int w, uint32_t v) const { base[(size_t)w * stride] = v; }
+    __device__ void orw(int w, uint32_t v) const { if (w >= 0 && w < wpc) base[(size_t)w * stride] |= v; }
+    __device__ void clear() const { for (int w = 0; w < wpc; w++) base[(size_t)w * stride] = 0; }
+};
+
+__device__ __forceinline__ uint32_t js_shl1(int n) { return 1u << (n & 31); }          // 1 << n in JavaScript
+
+// markRangeQ (cg2:170-184).  Words outside the column are dropped.
+__device__ __forceinline__ void mark_range_q(const BitCol& b, int q0, int q1) {
+    if (q1 <= q0) return;
+    const int w0 = (int)((unsigned)q0 >> 5), w1 = (int)((unsigned)(q1 - 1) >> 5);
+    const int s0 = q0 & 31, s1 = (q1 - 1) & 31;
+    if (w0 == w1) b.orw(w0, (~(js_shl1(s0) - 1u)) & (js_shl1(s1 + 1) - 1u));
+    else {
+        b.orw(w0, ~(js_shl1(s0) - 1u));
+        for (int w = w0 + 1; w < w1; w++) if (w < b.wpc) b.set(w, 0xFFFFFFFFu);
+        b.orw(w1, js_shl1(s1 + 1) - 1u);
+    }
+}
+
+// qZ of deposit_ALD (cg2:144-145) applied to a de-quantised integer height
+__device__ __forceinline__ int ald_requant(const GridView& g, unsigned q) { return (int)js_round(((double)q * g.zs) * g.inv_zs); }
+
+// markRange (cg2:185-190) for the integer interval [q0, q1) of a stored layer
+__device__ __forceinline__ void mark_layer(const GridView& g, const BitCol& b, unsigned z0q, unsigned z1q) {
+    int q0 = ald_requant(g, z0q); if (q0 < 0) q0 = 0;
+    int q1 = ald_requant(g, z1q); if (q1 <= q0) q1 = q0 + 1;
+    mark_range_q(b, q0, q1);
+}
+
+__device__ __forceinline__ int ctz32(uint32_t x) { return x ? __builtin_ctz(x) : 32; }
+
+// emitIntervals (cg2:197-324): f(s, e) for each run the reference reports, in its order.
+template <class F>
+__device__ __forceinline__ void emit_intervals(const BitCol& b, int Zmax, F&& f) {
+    bool inRun = false; int runStartQ = 0;
+    auto EMIT = [&](int sq, int eq) { const int s_ = min(sq, Zmax), e_ = min(eq, Zmax); if (e_ > s_) f(s_, e_); };
+    int qBase = 0;
+    for (int w = 0; w < b.wpc; w++, qBase += 32) {
+        uint32_t word = b.get(w);
+        if (!inRun) {
+            if (word == 0) continue;
+            while (word != 0) {
+                const int tz = ctz32(word);
+                const uint32_t v = word >> tz;
+                const int ones = ctz32(~v);
+                if (ones < 32 - tz) { EMIT(qBase + tz, qBase + tz + ones); word = v >> ones; }
+                else { runStartQ = qBase + tz; inRun = true; break; }
+            }
+        } else {
+            if (word == 0xFFFFFFFFu) continue;
+            if (word == 0) { EMIT(runStartQ, qBase); inRun = false; continue; }
+            const int prefixOnes = ctz32(~word);
+            EMIT(runStartQ, qBase + prefixOnes);               // prefixOnes == 0: the run ended on the word boundary
+            inRun = false;
+            uint32_t v = word >> prefixOnes;
+            while (v != 0) {
+                const int tz = ctz32(v);
+                v >>= tz;
+                const int sQ = qBase + prefixOnes + tz;
+                const int ones = ctz32(~v);
+                if (ones < 32) { EMIT(sQ, sQ + ones); v >>= ones; }
+                else { runStartQ = sQ; inRun = true; break; }
+            }
+        }
+    }
+    if (inRun) EMIT(runStartQ, Zmax);
+}
+
+// occupied bins of a column: layers of material >= 2 with positive thickness (cg2:338-364)
+__device__ __forceinline__ void mark_occupied(const GridView& g, size_t c, const BitCol& b) {
+    const int l = g.len[c];
+    unsigned prev = 0;
+    for (int k = 0; k < l; k++) {
+        const uint32_t r = g.rec[(size_t)k * g.N + c];
+        const unsigned z1 = rec_z1(r);
+        if (!rec_hole(r) && rec_mat(r) >= 2 && z1 > prev) mark_layer(g, b, prev, z1);
+        prev = z1;
+    }
+}
+
+struct AldLayout { int Zmax, wpc; uint32_t lastMask; };        // makeBitLayout (cg2:161-167), evaluated on the host
+
+// --- air intervals of every column (buildAirIntervalsAll, cg2:367-385) ---------------------
+// FILL = false: counts only (air_n); FILL = true: writes air[k*N + c] = (s, e) too.
+template <bool FILL>
+__global__ void k_ald_air(GridView g, AldLayout L, uint16_t* __restrict__ air_n, uint2* __restrict__ air, int planes,
+                          int* __restrict__ flags) {
+    extern __shared__ uint32_t lds[];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const BitCol b{lds + threadIdx.x, (int)blockDim.x, L.wpc};
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        b.clear();
+        mark_occupied(g, c, b);
+        for (int w = 0; w < L.wpc - 1; w++) b.set(w, ~b.get(w));
+        b.set(L.wpc - 1, (~b.get(L.wpc - 1)) & L.lastMask);
+        int n = 0;
+        emit_intervals(b, L.Zmax, [&](int s, int e) {
+            if (FILL && n < planes) air[(size_t)n * g.N + c] = make_uint2((unsigned)s, (unsigned)e);
+            n++;
+        });
+        if (!FILL) { air_n[c] = (uint16_t)min(n, 65535); if (n > flags[3]) atomicMax(&flags[3], n); }
+    }
+}
+
+// --- seeds (collectALDSeeds, cg2:405-463) ---------------------------------------------------
+__device__ __forceinline__ bool air_has_z(const uint16_t* air_n, const uint2* air, size_t N, size_t c, unsigned z) {
+    const int n = air_n[c];
+    for (int a = 0; a < n; a++) { const uint2 iv = air[(size_t)a * N + c]; if (z >= iv.x && z <= iv.y) return true; }
+    return false;
+}
+
+// FILL = false: seed_n only.  bbox = {imin, imax, jmin, jmax} of the columns that own a seed.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_ald_seeds(GridView g, unsigned H0q, const uint16_t* __restrict__ air_n, const uint2* __restrict__ air,
+                                                   uint16_t* __restrict__ seed_n, uint2* __restrict__ seed, int planes, int* __restrict__ bbox,
+                                                   int* __restrict__ flags, unsigned long long* __restrict__ total) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const int l = g.len[c];
+        const int i = (int)(c / g.ny), j = (int)(c - (size_t)i * g.ny);
+        int n = 0;
+        auto push = [&](unsigned a, unsigned b) {
+            if (FILL && n < planes) seed[(size_t)n * g.N + c] = make_uint2(a, b);
+            n++;
+        };
+        unsigned prev = 0;
+        for (int k = 0; k < l; k++) {
+            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            const unsigned z0 = prev, z1 = rec_z1(r);
+            prev = z1;
+            if (rec_hole(r) || rec_mat(r) < 3) continue;
+            if (air_has_z(air_n, air, g.N, c, z1) || z1 == H0q) push(z1, z1);                    // top face
+            if (z0 > 0 && air_has_z(air_n, air, g.N, c, z0)) push(z0, z0);                       // bottom face
+            const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {                                                       // side faces
+                const int ni = i + di[d], nj = j + dj[d];
+                if (ni < 0 || nj < 0 || ni >= g.nx || nj >= g.ny) continue;
+                if (z1 <= z0) continue;                                                         // intersectWith: v <= u + eps
+                const size_t nc = (size_t)ni * g.ny + nj;
+                const int na = air_n[nc];
+                for (int p = 0; p < na; p++) {
+                    const uint2 iv = air[(size_t)p * g.N + nc];
+                    if (iv.y <= z0) continue;
+                    if (iv.x >= z1) break;
+                    push(max(iv.x, z0), min(iv.y, z1));
+                }
+            }
+        }
+        if (!FILL) { seed_n[c] = (uint16_t)min(n, 65535); if (n > flags[3]) atomicMax(&flags[3], n); if (n) atomicAdd(total, (unsigned long long)n); }
+        else if (n > 0) { atomicMin(&bbox[0], i); atomicMax(&bbox[1], i); atomicMin(&bbox[2], j); atomicMax(&bbox[3], j); }
+    }
+}
+
+// --- inserting a bitset's runs into a column (applyCoatFromBits, cg2:585-682) ---------------
+struct AldOut {                                                // the adjacency pass, cg2:634-655
+    const GridView& g; ColWriter W; bool have = false; unsigned p0 = 0, p1 = 0; int pm = 0;
+    __device__ AldOut(const GridView& g_, const GridView& d, size_t c) : g(g_), W(d, c) {}
+    __device__ void flush() {
+        if (!have) return;
+        const int q0 = ald_requant(g, p0); int q1 = ald_requant(g, p1);
+        if (q1 <= q0) q1 = q0 + 1;
+        W.put((unsigned)q0, (unsigned)q1, pm);
+        have = false;
+    }
+    __device__ void put(unsigned z0, unsigned z1, int m) {
+        if (!have) { have = true; p0 = z0; p1 = z1; pm = m; return; }
+        if (z0 <= p1) {
+            if (pm == m) { if (z1 > p1) p1 = z1; }
+            else { const unsigned nz0 = max(z0, p1); if (z1 > nz0) { flush(); have = true; p0 = nz0; p1 = z1; pm = m; } }
+        } else { flush(); have = true; p0 = z0; p1 = z1; pm = m; }
+    }
+};
+
+// Column c of s, with the runs of `bits` inserted as material mat, written to d.
+__device__ __forceinline__ void insert_runs(const GridView& s, const GridView& d, size_t c, const BitCol& bits, int Zmax, int mat,
+                                            int* __restrict__ flags) {
+    bool any = false;
+    emit_intervals(bits, Zmax, [&](int, int) { any = true; });
+    if (!any) { copy_column(s, d, c, flags); return; }        // cg2:612
+    AldOut out(s, d, c);
+    const int l = s.len[c];
+    int k = 0; unsigned prev = 0;
+    // next layer of positive thickness at or after k: (a0, a1, am); k is left on it
+    unsigned a0 = 0, a1 = 0; int am = 0; bool haveA = false;
+    auto nextA = [&]() {
+        haveA = false;
+        while (k < l) {
+            const uint32_t r = s.rec[(size_t)k * s.N + c];
+            const unsigned z1 = rec_z1(r);
+            const unsigned z0 = prev;
+            prev = z1; k++;
+            if (!rec_hole(r) && z1 > z0) { a0 = z0; a1 = z1; am = rec_mat(r); haveA = true; return; }
+        }
+    };
+    nextA();
+    emit_intervals(bits, Zmax, [&](int bs, int be) {           // two-pointer merge, cg2:622-631
+        while (haveA && (a0 < (unsigned)bs || (a0 == (unsigned)bs && a1 <= (unsigned)be))) { out.put(a0, a1, am); nextA(); }
+        out.put((unsigned)bs, (unsigned)be, mat);
+    });
+    while (haveA) { out.put(a0, a1, am); nextA(); }
+    out.flush();
+    out.W.finish(d.len, flags);
+}
+
+struct AldTap { int du, dv; double add; };
+
+// --- coat at thickness t (computeCoatBitsSingleT + applyCoatFromBits, cg2:699-707, 585-682) --
+// bbox = the seeds' bounding box grown by the kernel radius and clipped to the domain (cg2:510-524).
+__global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, const AldTap* __restrict__ taps, int ntaps,
+                           const uint16_t* __restrict__ seed_n, const uint2* __restrict__ seed, int seed_planes,
+                           int imin, int imax, int jmin, int jmax, int mat, int* __restrict__ flags) {
+    extern __shared__ uint32_t lds[];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const BitCol fill{lds + threadIdx.x, (int)blockDim.x, L.wpc};
+    const BitCol occ{lds + (size_t)L.wpc * blockDim.x + threadIdx.x, (int)blockDim.x, L.wpc};
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < s.N; c += stride) {
+        const int i = (int)(c / s.ny), j = (int)(c - (size_t)i * s.ny);
+        fill.clear(); occ.clear();
+        if (i >= imin && i <= imax && j >= jmin && j <= jmax)
+            for (int t = 0; t < ntaps; t++) {
+                const int si = i - taps[t].du, sj = j - taps[t].dv;
+                if (si < 0 || sj < 0 || si >= s.nx || sj >= s.ny) continue;
+                const size_t sc = (size_t)si * s.ny + sj;
+                const int ns = min((int)seed_n[sc], seed_planes);
+                const double add = taps[t].add;
+                for (int q = 0; q < ns; q++) {                 // cg2:542-557
+                    const uint2 sd = seed[(size_t)q * s.N + sc];
+                    const double lo = (double)sd.x * s.zs - add, hi = (double)sd.y * s.zs + add;
+                    if (hi <= lo + CG_EPS) continue;
+                    const double z0 = lo > 0 ? lo : 0, z1 = hi < Hcap ? hi : Hcap;
+                    if (z1 <= z0 + CG_EPS) continue;
+                    double q0 = js_round(z0 * s.inv_zs); if (q0 < 0) q0 = 0;
+                    double q1 = js_round(z1 * s.inv_zs); if (q1 <= q0) q1 = q0 + 1;
+                    mark_range_q(fill, (int)q0, (int)q1);
+                }
+            }
+        mark_occupied(s, c, occ);
+        for (int w = 0; w < L.wpc - 1; w++) fill.set(w, fill.get(w) & ~occ.get(w));                      // cg2:566-582
+        fill.set(L.wpc - 1, fill.get(L.wpc - 1) & ((~occ.get(L.wpc - 1)) & L.lastMask));
+        insert_runs(s, d, c, fill, L.Zmax, mat, flags);
+    }
+}
+
+// --- keep only the cavities that appeared under the coat (mergeNewCavityFromTmp, cg2:766-814) --
+// Merged cavity intervals of a column, bottom to top (collectMatIntervals, cg2:710-742).
+struct CavIter {
+    const GridView& g; size_t c; int l, k = 0; unsigned prev = 0;
+    bool pend = false; unsigned p0 = 0, p1 = 0;
+    __device__ CavIter(const GridView& g_, size_t c_) : g(g_), c(c_), l(g_.len[c_]) {}
+    __device__ bool next(unsigned& a0, unsigned& a1) {
+        while (k < l) {
+            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            const unsigned z0 = prev, z1 = rec_z1(r);
+            prev = z1; k++;
+            if (rec_hole(r) || rec_mat(r) != 2 || z1 <= z0) continue;
+            if (!pend) { pend = true; p0 = z0; p1 = z1; continue; }
+            if (z0 <= p1) { if (z1 > p1) p1 = z1; continue; }
+            a0 = p0; a1 = p1; p0 = z0; p1 = z1;
+            return true;
+        }
+        if (pend) { pend = false; a0 = p0; a1 = p1; return true; }
+        return false;
+    }
+};
+
+// a = the state after coat + identify_cavity, b = the state before; d = b + (cavity(a) \ cavity(b))
+__global__ void k_ald_merge_cavity(GridView a, GridView b, GridView d, AldLayout L, int* __restrict__ flags) {
+    extern __shared__ uint32_t lds[];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const BitCol bits{lds + threadIdx.x, (int)blockDim.x, L.wpc};
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < a.N; c += stride) {
+        bits.clear();
+        auto mark = [&](unsigned z0, unsigned z1) {            // cg2:803-808
+            if (z1 <= z0) return;
+            int q0 = ald_requant(b, z0); if (q0 < 0) q0 = 0;
+            int q1 = ald_requant(b, z1); if (q1 <= q0) q1 = q0 + 1;
+            if (q1 > L.Zmax) q1 = L.Zmax;
+            mark_range_q(bits, q0, q1);
+        };
+        CavIter after(a, c);
+        unsigned s0, e0;
+        while (after.next(s0, e0)) {                           // diffIntervals, cg2:744-764
+            CavIter before(b, c);
+            unsigned bs, be, cur = s0;
+            bool done = false;
+            while (!done && before.next(bs, be)) {
+                if (be <= s0) continue;
+                if (!(bs < e0)) break;
+                if (bs > cur) mark(cur, min(bs, e0));
+                if (be > cur) cur = be;
+                if (cur >= e0) done = true;
+            }
+            if (cur < e0) mark(cur, e0);
+        }
+        insert_runs(b, d, c, bits, L.Zmax, 2, flags);
+    }
+}
+
+}  // namespace cgk

@@ -15,6 +15,7 @@
 
 #include "../../include/colgrid.h"
 #include "cg_kernels.hip.h"
+#include "cg_interval_kernels.hip.h"
 
 using namespace cgk;
 
@@ -100,6 +101,13 @@ struct cg_grid {
     double prof_ms[CG_NKIND] = {0}; uint64_t prof_cnt[CG_NKIND] = {0};
     // caller-owned halo buffers (cg_set_halo_buffers)
     bool halo_external = false;
+    // etch_wet / deposit_ALD write a second set of planes (ALD's cavity merge a third) and swap
+    uint8_t* alt_len[2] = {nullptr, nullptr}; uint32_t* alt_rec[2] = {nullptr, nullptr}; int alt_lmax[2] = {0, 0};
+    // deposit_ALD: seeds of the exposed faces (plane-major like the grid), their bounding box, the tap table
+    uint16_t* seed_n = nullptr; uint2* seed = nullptr; int seed_planes = 0; bool has_seeds = false;
+    int seed_bbox[4] = {0, -1, 0, -1}; uint64_t seed_total = 0;
+    int* d_bbox = nullptr;
+    AldTap* d_ald_taps = nullptr; int ald_taps_cap = 0;
     std::string err;
 };
 
@@ -433,6 +441,146 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
     return CG_OK;
 }
 
+
+// ---- second / third set of planes for the out-of-place models ---------------------------------
+void free_alt(cg_grid* g, int which) {
+    if (g->alt_len[which]) (void)hipFree(g->alt_len[which]);
+    if (g->alt_rec[which]) (void)hipFree(g->alt_rec[which]);
+    g->alt_len[which] = nullptr; g->alt_rec[which] = nullptr; g->alt_lmax[which] = 0;
+}
+
+// an all-empty set of planes as tall as the grid's
+int ensure_alt(cg_grid* g, int which) {
+    if (g->alt_rec[which] && g->alt_lmax[which] == g->lmax) return CG_OK;
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    free_alt(g, which);
+    const size_t S = g->N * (size_t)g->lmax;
+    HIPCHK(g, hipMalloc(&g->alt_len[which], std::max<size_t>(g->N, 4)));
+    HIPCHK(g, hipMalloc(&g->alt_rec[which], std::max<size_t>(4 * S, 4)));
+    HIPCHK(g, hipMemsetAsync(g->alt_len[which], 0, g->N, g->stream));
+    HIPCHK(g, hipMemsetAsync(g->alt_rec[which], 0, 4 * S, g->stream));
+    g->alt_lmax[which] = g->lmax;
+    return CG_OK;
+}
+
+GridView alt_view(const cg_grid* g, int which) {
+    GridView v = view(g);
+    v.len = g->alt_len[which]; v.rec = g->alt_rec[which]; v.lmax = g->alt_lmax[which];
+    return v;
+}
+
+void swap_alt(cg_grid* g, int which) {
+    std::swap(g->len, g->alt_len[which]); std::swap(g->rec, g->alt_rec[which]); std::swap(g->lmax, g->alt_lmax[which]);
+}
+
+// Run `launch(dst)` with dst = spare planes `which`, grow and repeat while a column does not
+// fit, then make dst the grid (the old planes become the spare set).
+template <class Launch>
+int run_out_of_place(cg_grid* g, int which, const char* what, Launch launch) {
+    for (int attempt = 0; attempt < 17; attempt++) {
+        int rc = ensure_alt(g, which); if (rc) return rc;
+        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+        launch(alt_view(g, which));
+        HIPCHK(g, hipGetLastError());
+        int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
+        if (fl[3] > 255 || fl[0])
+            return fail(g, CG_ERR_UNSUPPORTED, "%s: a column would need more than 255 intervals or layers that overlap", what);
+        if (fl[3] <= g->lmax) {
+            swap_alt(g, which);
+            g->len_bound = fl[3]; g->has_gaps = fl[2] != 0; g->has_cavity = fl[1] != 0;
+            return CG_OK;
+        }
+        rc = grow_planes(g, ((fl[3] - g->lmax + 15) / 16) * 16); if (rc) return rc;      // the spare set follows in ensure_alt
+    }
+    return fail(g, CG_ERR_STATE, "%s: plane growth did not converge", what);
+}
+
+// ---- deposit_ALD helpers -----------------------------------------------------------------------
+AldLayout make_bit_layout(const cg_grid* g, double HmaxPlus) {                  // script_columngrid2.js:161-167
+    const double hc = std::ceil(HmaxPlus / g->zscale);
+    AldLayout L;
+    L.Zmax = hc > 1 ? (hc < 2.0e9 ? (int)hc : 2000000000) : 1;
+    L.wpc = (int)(((unsigned)L.Zmax + 31u) >> 5);
+    const int lastBits = L.Zmax & 31;
+    L.lastMask = lastBits == 0 ? 0xFFFFFFFFu : ((1u << lastBits) - 1u);
+    return L;
+}
+
+// threads per block such that `nsets` bitsets of L.wpc words per thread fit 64 KiB of LDS
+int ald_block(const AldLayout& L, int nsets, size_t* lds_bytes) {
+    const size_t per_thread = (size_t)nsets * L.wpc * 4;
+    int bt = 256;
+    while (bt > 1 && bt * per_thread > 65536) bt >>= 1;
+    if (bt * per_thread > 65536) return 0;
+    *lds_bytes = bt * per_thread;
+    return bt;
+}
+
+unsigned ald_blocks(size_t n, int bt) { return (unsigned)std::min<size_t>(std::max<size_t>((n + bt - 1) / bt, 1), (size_t)1 << 20); }
+
+void drop_seeds(cg_grid* g) {
+    if (g->seed_n) (void)hipFree(g->seed_n);
+    if (g->seed) (void)hipFree(g->seed);
+    g->seed_n = nullptr; g->seed = nullptr; g->seed_planes = 0; g->has_seeds = false; g->seed_total = 0;
+    g->seed_bbox[0] = 0; g->seed_bbox[1] = -1; g->seed_bbox[2] = 0; g->seed_bbox[3] = -1;
+}
+
+// buildKernelRows (script_columngrid2.js:466-496) flattened to (du, dv, add)
+int build_ald_taps(const cg_grid* g, double t, std::vector<AldTap>* taps) {
+    const int Rx = js_to_int32(std::ceil(t / g->dx));
+    const double t2 = t * t;
+    taps->clear();
+    for (int du = -Rx; du <= Rx; du++) {
+        const double x = du * g->dx, x2 = x * x, rem = t2 - x2;
+        if (rem < 0) continue;
+        const int maxDv = js_to_int32(std::floor(std::sqrt(rem) / g->dy));
+        for (int dv = -maxDv; dv <= maxDv; dv++) {
+            const double y = dv * g->dy;
+            double add = rem - (y * y);
+            if (add < 0) add = 0;
+            taps->push_back(AldTap{du, dv, std::sqrt(add)});
+        }
+    }
+    return Rx;
+}
+
+// coat(t) from the held seeds, inserted as `mat`: the grid becomes grid + coat, spare set 0 keeps the grid as it was
+int ald_coat(cg_grid* g, int mat, double t) {
+    if (!g->has_seeds) return fail(g, CG_ERR_STATE, "deposit_ALD: no seeds held (cg_ald_collect_seeds first)");
+    unsigned qtop = 0;
+    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    const double Hnow = qtop > 0 ? (double)qtop * g->zscale : 1.0;                               // maxHeight()
+    const double Hcap = Hnow + t + g->zscale;                                                    // cg2:501, 702
+    const AldLayout L = make_bit_layout(g, Hcap);
+    size_t lds = 0;
+    const int bt = ald_block(L, 2, &lds);
+    if (!bt) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: %d height bins per column do not fit the bitsets", L.Zmax);
+    std::vector<AldTap> taps;
+    const int Rx = build_ald_taps(g, t, &taps);
+    if ((int)taps.size() > g->ald_taps_cap) {
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        if (g->d_ald_taps) (void)hipFree(g->d_ald_taps);
+        g->d_ald_taps = nullptr; g->ald_taps_cap = 0;
+        HIPCHK(g, hipMalloc(&g->d_ald_taps, taps.size() * sizeof(AldTap)));
+        g->ald_taps_cap = (int)taps.size();
+    }
+    if (!taps.empty()) {
+        HIPCHK(g, hipMemcpyAsync(g->d_ald_taps, taps.data(), taps.size() * sizeof(AldTap), hipMemcpyHostToDevice, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));            // taps is a local
+    }
+    int imin = 1, imax = 0, jmin = 1, jmax = 0;                // no seed: nothing is filled (cg2:517)
+    if (g->seed_bbox[1] >= g->seed_bbox[0]) {                  // cg2:521-524 (both directions grow by Rx)
+        imin = std::max(0, g->seed_bbox[0] - Rx); imax = std::min(g->nx - 1, g->seed_bbox[1] + Rx);
+        jmin = std::max(0, g->seed_bbox[2] - Rx); jmax = std::min(g->ny - 1, g->seed_bbox[3] + Rx);
+    }
+    const int ntaps = (int)taps.size();
+    ProfScope ps(g, CG_K_OTHER);
+    return run_out_of_place(g, 0, "deposit_ALD", [&](GridView dst) {
+        hipLaunchKernelGGL(k_ald_coat, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), dst, L, Hcap, g->d_ald_taps, ntaps,
+                           g->seed_n, g->seed, g->seed_planes, imin, imax, jmin, jmax, mat, g->d_flags);
+    });
+}
+
 }  // namespace
 
 template <bool ETCH>
@@ -473,6 +621,7 @@ int cg_create_slab(int nx_global, int ny, int i0, int nx_local, double dx, doubl
         HIPCHK(g, hipMalloc(&g->d_flags, 4 * sizeof(int)));
         HIPCHK(g, hipMalloc(&g->d_red, 4 * sizeof(unsigned)));
         HIPCHK(g, hipMalloc(&g->d_sum, sizeof(unsigned long long)));
+        HIPCHK(g, hipMalloc(&g->d_bbox, 4 * sizeof(int)));
         HIPCHK(g, hipMalloc(&g->d_stats, CG_NSTAT * sizeof(unsigned long long)));
         HIPCHK(g, hipMemset(g->d_flags, 0, 4 * sizeof(int)));
         HIPCHK(g, hipMemset(g->d_stats, 0, CG_NSTAT * sizeof(unsigned long long)));
@@ -512,6 +661,9 @@ int cg_destroy(cg_grid* g) {
     if (g->d_flags) (void)hipFree(g->d_flags);
     if (g->d_red) (void)hipFree(g->d_red);
     if (g->d_sum) (void)hipFree(g->d_sum);
+    if (g->d_bbox) (void)hipFree(g->d_bbox);
+    if (g->d_ald_taps) (void)hipFree(g->d_ald_taps);
+    free_alt(g, 0); free_alt(g, 1); drop_seeds(g);
     if (g->d_stats) (void)hipFree(g->d_stats);
     if (g->sl_mat) (void)hipFree(g->sl_mat);
     if (g->sl_zp) (void)hipFree(g->sl_zp);
@@ -837,6 +989,195 @@ int cg_identify_cavity(cg_grid* g) {
     }
     if (g->len_bound < 255) g->len_bound += 1;
     return cg_strip_connected(g, CG_MAT_CAVITY);                                    // cg2:79
+}
+
+// ---- etch_wet (script_columngrid2.js:893 - script_columngrid3.js:308) --------------------------
+int cg_etch_wet_step(cg_grid* g, int mat, int dt_q, int use_diagonal) {
+    NEED(g);
+    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "etch_wet on a slab of a decomposed domain is not built yet");
+    if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
+    if (dt_q < 1) return fail(g, CG_ERR_ARG, "etch_wet increment of %d height steps", dt_q);
+    g->pend.active = false;
+    unsigned qtop = 0;
+    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    const unsigned Hq = std::max(qtop, 1u);                                                      // cg3:8
+    const int dt_diag = std::max(1, (int)std::floor(dt_q * 0.7071067811865476));                 // cg3:92
+    {
+        ProfScope ps(g, CG_K_OTHER);
+        rc = run_out_of_place(g, 0, "etch_wet", [&](GridView dst) {
+            hipLaunchKernelGGL(k_wet_step, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), dst, mat, dt_q, dt_diag,
+                               use_diagonal ? 1 : 0, Hq, g->d_flags);
+        });
+        if (rc) return rc;
+    }
+    return cg_identify_cavity(g);                                                                // cg3:267
+}
+
+int cg_etch_wet(cg_grid* g, int mat, double total_thickness, double dt) {
+    NEED(g);
+    const double T = std::isnan(total_thickness) ? 0 : std::max(0.0, total_thickness);           // cg2:894-895
+    if (T <= 0) return CG_OK;
+    double base_dt = std::isnan(dt) ? std::min(g->dx, g->dy) : dt;                               // cg2:905
+    if (!(base_dt > 1e-6)) base_dt = 1e-6;
+    double R = 0, t = 0;
+    int rc = CG_OK;
+    while (t < T - 1e-9) {                                                                       // cg3:286-306
+        R += 0.7071067811865476;
+        int diag = 0;
+        if (R > 1) { R -= 1; diag = 1; }
+        const double dt_real = std::min(base_dt, T - t);
+        int dt_q = js_to_int32(js_round(dt_real / g->zscale));
+        if (dt_q < 1) dt_q = 1;
+        rc = cg_etch_wet_step(g, mat, dt_q, diag); if (rc) break;
+        t += (double)dt_q * g->zscale;
+    }
+    if (!rc) rc = cg_identify_cavity(g);                                                         // cg3:307
+    cg_release_scratch(g);
+    return rc;
+}
+
+// ---- deposit_ALD (script_columngrid2.js:111-868) -----------------------------------------------
+int cg_ald_collect_seeds(cg_grid* g, double total_thickness, uint64_t* count) {
+    NEED(g);
+    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD on a slab of a decomposed domain is not built yet");
+    if (!(total_thickness > 0)) return fail(g, CG_ERR_ARG, "deposit_ALD thickness %g", total_thickness);
+    unsigned qtop = 0;
+    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    const double H0 = qtop > 0 ? (double)qtop * g->zscale : 1.0;
+    const AldLayout L = make_bit_layout(g, H0 + total_thickness + g->zscale);                    // cg2:408
+    size_t lds = 0;
+    const int bt = ald_block(L, 1, &lds);
+    if (!bt) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: %d height bins per column do not fit the bitsets", L.Zmax);
+    drop_seeds(g);
+    ProfScope ps(g, CG_K_OTHER);
+    uint16_t* air_n = nullptr; uint2* air = nullptr;
+    auto cleanup = [&]() { if (air_n) (void)hipFree(air_n); if (air) (void)hipFree(air); };
+    auto body = [&]() -> int {
+        int fl[4];
+        HIPCHK(g, hipMalloc(&air_n, std::max<size_t>(2 * g->N, 4)));
+        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+        hipLaunchKernelGGL(k_ald_air<false>, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), L, air_n, (uint2*)nullptr, 0, g->d_flags);
+        HIPCHK(g, hipGetLastError());
+        int r = read_flags(g, fl); if (r) return r;
+        const int air_planes = std::max(1, fl[3]);
+        if (air_planes > 65535) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: more than 65535 air intervals in a column");
+        HIPCHK(g, hipMalloc(&air, (size_t)air_planes * g->N * sizeof(uint2)));
+        hipLaunchKernelGGL(k_ald_air<true>, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), L, air_n, air, air_planes, g->d_flags);
+        HIPCHK(g, hipGetLastError());
+        // seeds: count, then fill
+        const unsigned H0q = qtop > 0 ? qtop : 0xFFFFFFFFu;                                      // |z1 - maxHeight()| < eps (cg2:440)
+        HIPCHK(g, hipMalloc(&g->seed_n, std::max<size_t>(2 * g->N, 4)));
+        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+        HIPCHK(g, hipMemsetAsync(g->d_sum, 0, sizeof(unsigned long long), g->stream));
+        const dim3 grid(blocks_for(g->N)), blk(256);
+        hipLaunchKernelGGL(k_ald_seeds<false>, grid, blk, 0, g->stream, view(g), H0q, air_n, air, g->seed_n, (uint2*)nullptr, 0, g->d_bbox, g->d_flags, g->d_sum);
+        HIPCHK(g, hipGetLastError());
+        r = read_flags(g, fl); if (r) return r;
+        unsigned long long total = 0;
+        HIPCHK(g, hipMemcpy(&total, g->d_sum, sizeof total, hipMemcpyDeviceToHost));
+        if (fl[3] > 65535) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: more than 65535 seeds in a column");
+        g->seed_planes = std::max(1, fl[3]);
+        HIPCHK(g, hipMalloc(&g->seed, (size_t)g->seed_planes * g->N * sizeof(uint2)));
+        const int bb0[4] = {INT32_MAX, -1, INT32_MAX, -1};
+        HIPCHK(g, hipMemcpyAsync(g->d_bbox, bb0, sizeof bb0, hipMemcpyHostToDevice, g->stream));
+        hipLaunchKernelGGL(k_ald_seeds<true>, grid, blk, 0, g->stream, view(g), H0q, air_n, air, g->seed_n, g->seed, g->seed_planes, g->d_bbox, g->d_flags, g->d_sum);
+        HIPCHK(g, hipGetLastError());
+        HIPCHK(g, hipMemcpyAsync(g->seed_bbox, g->d_bbox, sizeof bb0, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        g->seed_total = total; g->has_seeds = true;
+        return CG_OK;
+    };
+    rc = body();
+    (void)hipStreamSynchronize(g->stream);
+    cleanup();
+    if (rc) { drop_seeds(g); return rc; }
+    if (count) *count = g->seed_total;
+    return CG_OK;
+}
+
+int cg_ald_seed_info(cg_grid* g, int* held, uint64_t* count) {
+    if (!g) return fail(nullptr, CG_ERR_ARG, "null handle");
+    if (held) *held = g->has_seeds ? 1 : 0;
+    if (count) *count = g->has_seeds ? g->seed_total : 0;
+    return CG_OK;
+}
+
+int cg_ald_drop_seeds(cg_grid* g) {
+    NEED(g);
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    drop_seeds(g);
+    return CG_OK;
+}
+
+int cg_ald_coat(cg_grid* g, int mat, double t) {
+    NEED(g);
+    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD on a slab of a decomposed domain is not built yet");
+    if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
+    if (!(t > 0)) return fail(g, CG_ERR_ARG, "deposit_ALD coat thickness %g", t);
+    g->pend.active = false;
+    return ald_coat(g, mat, t);
+}
+
+int cg_ald_increment(cg_grid* g, int mat, double t) {
+    int rc = cg_ald_coat(g, mat, t); if (rc) return rc;                 // grid = base + coat(t); spare set 0 = base  (cg2:844-848)
+    // layout of the merge: makeBitLayout(maxHeight(base) + zScale) (cg2:791); base's height was the grid's before the coat
+    unsigned qtop_base = 0;
+    {
+        GridView b = alt_view(g, 0);
+        HIPCHK(g, hipMemsetAsync(g->d_red, 0, 2 * sizeof(unsigned), g->stream));
+        hipLaunchKernelGGL(k_max_top, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, b, g->d_red);
+        HIPCHK(g, hipGetLastError());
+        unsigned r[2];
+        HIPCHK(g, hipMemcpyAsync(r, g->d_red, sizeof r, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        qtop_base = r[0];
+    }
+    rc = cg_identify_cavity(g); if (rc) return rc;                      // cg2:851
+    const double Hbase = qtop_base > 0 ? (double)qtop_base * g->zscale : 1.0;
+    const AldLayout L = make_bit_layout(g, Hbase + g->zscale);
+    size_t lds = 0;
+    const int bt = ald_block(L, 1, &lds);
+    if (!bt) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: %d height bins per column do not fit the bitsets", L.Zmax);
+    // base + (cavities of the coated grid that base does not have) -> spare set 1 -> the grid  (cg2:854)
+    ProfScope ps(g, CG_K_OTHER);
+    const GridView base = alt_view(g, 0);
+    for (int attempt = 0; attempt < 17; attempt++) {
+        rc = ensure_alt(g, 1); if (rc) return rc;
+        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+        hipLaunchKernelGGL(k_ald_merge_cavity, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), base, alt_view(g, 1), L, g->d_flags);
+        HIPCHK(g, hipGetLastError());
+        int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
+        if (fl[3] > 255 || fl[0]) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: a column would need more than 255 intervals or layers that overlap");
+        if (fl[3] <= g->lmax) {
+            swap_alt(g, 1);
+            g->len_bound = fl[3]; g->has_gaps = fl[2] != 0; g->has_cavity = fl[1] != 0;
+            return CG_OK;
+        }
+        rc = grow_planes(g, ((fl[3] - g->lmax + 15) / 16) * 16); if (rc) return rc;
+    }
+    return fail(g, CG_ERR_STATE, "deposit_ALD: plane growth did not converge");
+}
+
+int cg_deposit_ald(cg_grid* g, int mat, double total_thickness, double dt) {
+    NEED(g);
+    const double T = std::isnan(total_thickness) ? 0 : std::max(0.0, total_thickness);           // cg2:112-113
+    if (T <= 0) return CG_OK;
+    double step = std::isnan(dt) ? std::max(std::max(g->dx, g->dy), std::min(g->dx, g->dy)) : dt;   // cg2:124-127
+    if (!(step > 1e-3)) step = 1e-3;
+    int rc = cg_ald_collect_seeds(g, T, nullptr);
+    for (double t = step; !rc && t < T - 1e-9; t += step) rc = cg_ald_increment(g, mat, t);      // cg2:843-858
+    if (!rc) rc = cg_ald_coat(g, mat, T);                                                        // cg2:861-862
+    if (!rc) rc = cg_identify_cavity(g);                                                         // cg2:867
+    cg_release_scratch(g);
+    if (g) { (void)hipStreamSynchronize(g->stream); drop_seeds(g); }
+    return rc;
+}
+
+int cg_release_scratch(cg_grid* g) {
+    NEED(g);
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    free_alt(g, 0); free_alt(g, 1);
+    return CG_OK;
 }
 
 int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q) {

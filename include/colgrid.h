@@ -157,6 +157,42 @@ int cg_strip_connected(cg_grid* g, int mat);
 /* identify_cavity() (cg2:9-83). */
 int cg_identify_cavity(cg_grid* g);
 
+/* etch_wet(matId, totalThk, {dt}) without the slider cache (cg2:893 - cg3:308): isotropic
+ * removal of `mat` (255 = every solid, id >= 3) in increments of dt nm, each followed by
+ * identify_cavity.  total_thickness <= 0: no-op.  dt = NaN: the reference's default
+ * min(dx, dy).  Frees the engine's scratch planes before it returns. */
+int cg_etch_wet(cg_grid* g, int mat, double total_thickness, double dt);
+
+/* One increment of etch_wet: stepOnce(dtQ, useDiagonal) (cg3:250-268), identify_cavity
+ * included.  dt_q >= 1 is the increment in height steps.  A host that keeps the reference's
+ * anchors (sliderCache.wetetchCache, cg3:272-306) drives the loop itself with this call,
+ * cg_snapshot_save/load and cg_release_scratch. */
+int cg_etch_wet_step(cg_grid* g, int mat, int dt_q, int use_diagonal);
+
+/* deposit_ALD(matId, totalThk, {dt}) without the slider cache (cg2:111-868): seeds on every
+ * exposed face, a coat of thickness t grown from them for t = dt, 2dt, ... < total (only the
+ * cavities it pinches off are kept), then the final coat and identify_cavity.
+ * dt = NaN: the reference's default max(dx, dy).  Frees the scratch planes and the seeds. */
+int cg_deposit_ald(cg_grid* g, int mat, double total_thickness, double dt);
+
+/* The pieces of deposit_ALD for a host that keeps the reference's cache
+ * (sliderCache.aldCache, cg2:131-136, 821-865):
+ *   cg_ald_collect_seeds  collectALDSeeds (cg2:405-463) for the current grid; the seeds stay
+ *                         in the handle until replaced or dropped.  count may be NULL.
+ *   cg_ald_seed_info      are seeds held, and how many.
+ *   cg_ald_increment      one pass of the loop body cg2:844-854 at thickness t.
+ *   cg_ald_coat           computeCoatBitsSingleT + applyCoatFromBits at thickness t
+ *                         (cg2:861-862); the caller snapshots, then calls cg_identify_cavity. */
+int cg_ald_collect_seeds(cg_grid* g, double total_thickness, uint64_t* count);
+int cg_ald_seed_info(cg_grid* g, int* held, uint64_t* count);
+int cg_ald_drop_seeds(cg_grid* g);
+int cg_ald_increment(cg_grid* g, int mat, double t);
+int cg_ald_coat(cg_grid* g, int mat, double t);
+
+/* Frees the second and third set of planes that etch_wet / deposit_ALD steps work in
+ * (they are as large as the grid itself).  No counterpart in the reference. */
+int cg_release_scratch(cg_grid* g);
+
 /* maxHeight() (cg2:85-104): max top z over this handle's columns in nm, 1 if that is 0.
  * top_q receives the quantised maximum (0 for an empty grid); either pointer may be NULL. */
 int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q);

@@ -50,6 +50,8 @@ def test_golden_steps(name):
     def check(idx, s):
         assert g.Lmax == s["lmax"], f"{name} step {idx}"
         assert g.maxHeight() == s["max_height"], f"{name} step {idx}"
+        if "slider" in s:
+            assert g.slider_sizes() == (len(s["slider"]["ald_keys"]), len(s["slider"]["wet_keys"]), s["slider"]["seeds"])
         if "dump_index" in s:
             ln, mat, zp, lm = case["dump_arrays"][s["dump_index"]]
             _assert_same(g, (ln, mat, zp), f"{name} step {idx} {s['op']}")
@@ -204,6 +206,76 @@ def test_random_flow_with_strip_cmp_cavity_vs_oracle(nx, ny, seed):
     g2.deposit_general(None, 8, 5, 1.0); o.deposit_general(None, 8, 5, 1.0)
     assert g2.checksum() == o.checksum()
     g.close(); g2.close()
+
+
+@pytest.mark.parametrize("nx,ny,seed", [(96, 128, 21), (150, 77, 22)])
+def test_random_flow_with_wet_etch_and_ald_vs_oracle(nx, ny, seed):
+    """etch_wet and deposit_ALD mixed with the other step kinds, against the oracle step by step:
+    undercuts, pinched-off cavities, thin layers, every-solid targets, non-default increments."""
+    fem = _engine()
+    rng = _lcg(seed)
+    L = 2 * max(nx, ny)
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    g.keep_step_snapshots = False
+    masks = []
+    for _ in range(3):
+        red = fem.reduce_mask(_random_mask_data(rng, L, 10))
+        masks.append((g.mask_from_shapes(red), o.mask_raster(red)))
+    steps = [("d", None, 3, 20, 0), ("d", None, 4, 6, 0), ("d", None, 5, 1.3, 0), ("d", None, 4, 0.7, 0), ("d", None, 5, 12, 0),
+             ("e", 0, 255, 25, 0), ("w", None, 4, 3, None), ("a", None, 6, 3, None), ("e", 1, 255, 18, 0),
+             ("w", None, 255, 2.5, None), ("a", None, 7, 5, None), ("d", None, 3, 4, 1.0), ("w", None, 3, 4.2, 1.5),
+             ("e", 2, 255, 40, 0), ("a", None, 4, 2.7, 0.9), ("p", None, 0, 5, 0), ("w", None, 7, 1.1, 0.3),
+             ("a", None, 5, 0.35, None), ("s", None, 4, 0, 0), ("a", None, 8, 6.5, 2.5), ("w", None, 255, 3, None)]
+    for idx, (kind, mi, mat, t, S) in enumerate(steps):
+        gm, om = (None, None) if mi is None else masks[mi]
+        if kind == "d":
+            g.deposit_general(gm, mat, t, S); o.deposit_general(om, mat, t, S)
+        elif kind == "e":
+            g.etch_general(gm, mat, t, S); o.etch_general(om, mat, t, S)
+        elif kind == "s":
+            g.strip_connected(mat); o.strip_connected(mat)
+        elif kind == "p":
+            g.cmp(t, mat); o.cmp(t, mat)
+        elif kind == "w":
+            g.etch_wet(mat, t, dt=S); o.etch_wet(mat, t, dt=S)
+        elif kind == "a":
+            g.deposit_ALD(mat, t, dt=S); o.deposit_ALD(mat, t, dt=S)
+            assert g.slider_sizes()[2] == o.slider_sizes()[2], f"step {idx}: seeds"
+        assert g.checksum() == o.checksum(), f"step {idx} {kind} mat={mat} t={t} S={S} mask={mi}"
+        assert g.maxHeight() == o.max_height()
+        assert o.arrays()[0].max() < o.Lmax, "the reference loses its state when a column fills every slot"
+    ln, mat, zp = g.download()
+    oln, omat, ozp = o.arrays()
+    L0 = min(g.Lmax, o.Lmax)
+    np.testing.assert_array_equal(ln, oln)
+    np.testing.assert_array_equal(mat.reshape(-1, g.Lmax)[:, :L0], omat.reshape(-1, o.Lmax)[:, :L0])
+    np.testing.assert_array_equal(zp.reshape(-1, g.Lmax, 2)[:, :L0], ozp.reshape(-1, o.Lmax, 2)[:, :L0])
+    g.close()
+
+
+def test_wet_etch_and_ald_whole_run_entry_points():
+    """cg_etch_wet / cg_deposit_ald (the loops inside the library) equal the oracle's uncached runs."""
+    fem = _engine()
+    g = fem.ColumnGrid(128, 96, 2, 2)
+    o = OracleGrid(128, 96, 2, 2)
+    red = fem.reduce_mask({"objects": [{"type": "rect", "left": 0, "top": 0, "width": 400, "height": 400, "visible": True, "data": {"polarity": "positive"}},
+                                       {"type": "rect", "left": 30, "top": 10, "width": 12, "height": 60, "visible": True, "data": {"polarity": "negative"}},
+                                       {"type": "circle", "left": 70, "top": 30, "width": 16, "height": 16, "radius": 8, "visible": True, "data": {"polarity": "negative"}}]})
+    gm, om = g.mask_from_shapes(red), o.mask_raster(red)
+    for mat, t in ((3, 20), (4, 7), (5, 11)):
+        g.deposit_general(None, mat, t, 0); o.deposit_general(None, mat, t, 0)
+    g.etch_general(gm, 255, 24, 0); o.etch_general(om, 255, 24, 0)
+    nan = float("nan")
+    for fn, args in (("cg_etch_wet", (4, 5.0, nan)), ("cg_deposit_ald", (6, 4.0, nan)), ("cg_etch_wet", (255, 2.2, 0.7)),
+                     ("cg_deposit_ald", (7, 3.3, 1.0)), ("cg_etch_wet", (6, 0.0, nan)), ("cg_deposit_ald", (7, -1.0, nan))):
+        g._chk(getattr(g.lib, fn)(g.h, *args))
+        dt = None if args[2] != args[2] else args[2]
+        (o.etch_wet if fn == "cg_etch_wet" else o.deposit_ALD)(args[0], args[1], dt=dt)
+        o.slider_reset()
+        assert g.checksum() == o.checksum(), (fn, args)
+    _assert_same(g, o.arrays(), "whole-run entry points")
+    g.close()
 
 
 def test_upload_download_roundtrip_and_slices():
