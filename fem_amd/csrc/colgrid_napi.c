@@ -235,6 +235,57 @@ static napi_value js_max_height(napi_env env, napi_callback_info info) {        
     napi_value v; napi_create_double(env, z, &v); return v;
 }
 
+/* ---- etch_wet / deposit_ALD ------------------------------------------------------------------ */
+static napi_value js_etch_wet_step(napi_env env, napi_callback_info info) {      /* cg_etch_wet_step */
+    ARGS(env, info, 4);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t mat, dtq, diag;
+    if (!get_int(env, argv[1], &mat) || !get_int(env, argv[2], &dtq) || !get_int(env, argv[3], &diag)) return NULL;
+    int rc = cg_etch_wet_step(g, mat, dtq, diag); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+static napi_value whole_run(napi_env env, napi_callback_info info, int (*fn)(cg_grid*, int, double, double)) {
+    ARGS(env, info, 4);                                                          /* (handle, mat, total, dt or NaN) */
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t mat; double total, dt;
+    if (!get_int(env, argv[1], &mat) || !get_double(env, argv[2], &total) || !get_double(env, argv[3], &dt)) return NULL;
+    int rc = fn(g, mat, total, dt); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+static napi_value js_etch_wet(napi_env env, napi_callback_info info) { return whole_run(env, info, cg_etch_wet); }        /* cg_etch_wet */
+static napi_value js_deposit_ald(napi_env env, napi_callback_info info) { return whole_run(env, info, cg_deposit_ald); }  /* cg_deposit_ald */
+
+static napi_value js_ald_collect_seeds(napi_env env, napi_callback_info info) {  /* cg_ald_collect_seeds -> seed count */
+    ARGS(env, info, 2);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    double total; if (!get_double(env, argv[1], &total)) return NULL;
+    uint64_t n = 0;
+    int rc = cg_ald_collect_seeds(g, total, &n); if (rc) return throw_cg(env, g, rc);
+    napi_value v; napi_create_double(env, (double)n, &v); return v;
+}
+static napi_value js_ald_drop_seeds(napi_env env, napi_callback_info info) {     /* cg_ald_drop_seeds */
+    ARGS(env, info, 1);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int rc = cg_ald_drop_seeds(g); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+static napi_value ald_at(napi_env env, napi_callback_info info, int (*fn)(cg_grid*, int, double)) {
+    ARGS(env, info, 3);                                                          /* (handle, mat, t) */
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t mat; double t;
+    if (!get_int(env, argv[1], &mat) || !get_double(env, argv[2], &t)) return NULL;
+    int rc = fn(g, mat, t); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+static napi_value js_ald_increment(napi_env env, napi_callback_info info) { return ald_at(env, info, cg_ald_increment); }   /* cg_ald_increment */
+static napi_value js_ald_coat(napi_env env, napi_callback_info info) { return ald_at(env, info, cg_ald_coat); }             /* cg_ald_coat */
+static napi_value js_release_scratch(napi_env env, napi_callback_info info) {    /* cg_release_scratch */
+    ARGS(env, info, 1);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int rc = cg_release_scratch(g); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+
 /* ---- data exchange ------------------------------------------------------------------------- */
 static napi_value js_download(napi_env env, napi_callback_info info) {           /* cg_download */
     ARGS(env, info, 1);
@@ -331,6 +382,9 @@ static napi_value init(napi_env env, napi_value exports) {
         {"snapshotSave", js_snapshot_save}, {"snapshotLoad", js_snapshot_load}, {"snapshotDrop", js_snapshot_drop},
         {"slices", js_slices}, {"indexFromPos", js_index_from_pos}, {"checksum", js_checksum}, {"version", js_version},
         {"shapeBytes", js_shape_bytes},
+        {"etchWetStep", js_etch_wet_step}, {"etchWet", js_etch_wet}, {"depositAld", js_deposit_ald},
+        {"aldCollectSeeds", js_ald_collect_seeds}, {"aldDropSeeds", js_ald_drop_seeds}, {"aldIncrement", js_ald_increment},
+        {"aldCoat", js_ald_coat}, {"releaseScratch", js_release_scratch},
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;

@@ -11,6 +11,9 @@
 //    the reference's closure maskFn(x, y); a closure made by maskFunctionFor() carries the mask
 //    record's shape list and is rasterised by the device kernel, any other closure is evaluated
 //    here at every cell centre (cg1:448) into a byte raster and uploaded;
+//  * deposit_ALD / etch_wet keep their per-increment anchors (sliderCache.aldCache /
+//    sliderCache.wetetchCache, cg2:131-136, 911) as device snapshots and the ALD seeds in the
+//    handle; replacing `sliderCache` (script_runtime.js:275) releases them;
 //  * saveCache keeps device snapshots (with their Lmax -- the reference forgets it, cg1:229-235
 //    vs 276-279) and the same [snapshot, useCount] bookkeeping the runtime pokes at.
 'use strict';
@@ -40,8 +43,24 @@ class ColumnGrid {
     this._maskIds = new Map();          // reduced-shape JSON -> device mask id
     this._nextSlot = 0;
     this.colsCache = {};
-    this.sliderCache = {};
+    this._sliderCache = {};
+    this.keepStepSnapshots = true;      // the reference stores a grid copy per ALD / wet-etch increment
     this._refreshInfo();
+  }
+
+  // sliderCache is a plain object for its users; the device snapshots and seeds it stands for
+  // are released when it is replaced (cg1:244, script_runtime.js:275).
+  get sliderCache() { return this._sliderCache; }
+  set sliderCache(v) {
+    const old = this._sliderCache;
+    if (old && old !== v && this._h) {
+      if (old.wetetchCache) for (const e of old.wetetchCache.grid.values()) addon.snapshotDrop(this._h, e.slot);
+      if (old.aldCache) {
+        for (const e of old.aldCache.gridWithCavity.values()) addon.snapshotDrop(this._h, e.slot);
+        addon.aldDropSeeds(this._h);
+      }
+    }
+    this._sliderCache = v || {};
   }
 
   _refreshInfo() {
@@ -125,8 +144,81 @@ class ColumnGrid {
   strip_connected(matId) { addon.stripConnected(this._h, matId | 0); this._touched(); }                  // cg1:867
   identify_cavity() { addon.identifyCavity(this._h); this._touched(); }                                  // cg2:9
   maxHeight() { return addon.maxHeight(this._h); }                                                       // cg2:85
-  deposit_ALD() { throw new Error('deposit_ALD is not available in the GPU engine yet'); }                // cg2:111
-  etch_wet() { throw new Error('etch_wet is not available in the GPU engine yet'); }                      // cg2:893
+
+  _anchorAtOrBelow(map, T) {                                         // cg2:832-835, cg3:274-277
+    let best = -1;
+    for (const k of map.keys()) if (k <= T + 1e-9 && k > best) best = k;
+    return best;
+  }
+  _saveAnchor(map, key) {
+    if (!this.keepStepSnapshots) return;
+    let e = map.get(key);
+    if (!e) { e = { slot: this._nextSlot++ }; map.set(key, e); }
+    addon.snapshotSave(this._h, e.slot);
+  }
+
+  // deposit_ALD(matId, totalThk, { dt, isCache }) (cg2:111-868)
+  deposit_ALD(matId, totalThk, opts = {}) {
+    const T = Math.max(0, Number(totalThk) || 0);
+    if (T <= 0) return;
+    const zStepNm = this._zStepNm || Math.min(this.dx, this.dy);
+    const dt = Math.max(opts.dt === undefined || opts.dt === null ? Math.max(this.dx, this.dy, zStepNm) : opts.dt, 1e-3);
+    const isCache = !!opts.isCache;
+    const sc = this._sliderCache;
+    sc.aldCache = sc.aldCache || { exposedSegments: null, gridWithCavity: new Map(), BitsCache: {} };
+    const ac = sc.aldCache;
+    try {
+      if (!(isCache && ac.exposedSegments)) ac.exposedSegments = { count: addon.aldCollectSeeds(this._h, T) };
+      let tAnchor = 0;
+      if (isCache && ac.gridWithCavity.size > 0) {
+        const best = this._anchorAtOrBelow(ac.gridWithCavity, T);
+        if (best >= 0) { addon.snapshotLoad(this._h, ac.gridWithCavity.get(best).slot); tAnchor = best; }
+      }
+      for (let t = tAnchor + dt; t < T - 1e-9; t += dt) {
+        addon.aldIncrement(this._h, matId | 0, t);
+        this._saveAnchor(ac.gridWithCavity, t);
+      }
+      addon.aldCoat(this._h, matId | 0, T);
+      this._saveAnchor(ac.gridWithCavity, T);
+      addon.identifyCavity(this._h);
+    } finally {
+      addon.releaseScratch(this._h);
+      this._touched();
+    }
+  }
+
+  // etch_wet(matId, totalThk, { dt, isCache }) (cg2:893 - cg3:308)
+  etch_wet(matId, totalThk, opts = {}) {
+    const T = Math.max(0, Number(totalThk) || 0);
+    if (T <= 0) return;
+    const baseDt = Math.max(opts.dt === undefined || opts.dt === null ? Math.min(this.dx, this.dy) : opts.dt, 1e-6);
+    const isCache = !!opts.isCache;
+    const INV_SQRT2 = 0.7071067811865476;
+    const sc = this._sliderCache;
+    sc.wetetchCache = sc.wetetchCache || { grid: new Map(), R: 0 };
+    const wc = sc.wetetchCache;
+    let R = 0, t = 0;
+    try {
+      if (isCache && wc.grid.size > 0) {
+        const best = this._anchorAtOrBelow(wc.grid, T);
+        if (best >= 0) { addon.snapshotLoad(this._h, wc.grid.get(best).slot); R = Number(wc.R) || 0; t = best; }
+      }
+      while (t < T - 1e-9) {
+        R += INV_SQRT2;
+        let useDiagonal = false;
+        if (R > 1) { R -= 1; useDiagonal = true; }
+        const dtQ = Math.max(1, this._quantizeZ(Math.min(baseDt, T - t)) | 0);
+        addon.etchWetStep(this._h, matId | 0, dtQ, useDiagonal ? 1 : 0);
+        t += this._dequantizeZ(dtQ);
+        this._saveAnchor(wc.grid, t);
+        wc.R = R;
+      }
+      addon.identifyCavity(this._h);
+    } finally {
+      addon.releaseScratch(this._h);
+      this._touched();
+    }
+  }
 
   // ---- grid lifetime
   createNewGrid(LmaxInit = this.Lmax) { addon.reset(this._h, LmaxInit | 0); this._touched(); }            // cg1:40
@@ -145,7 +237,7 @@ class ColumnGrid {
   initializeCache() {
     for (const k of Object.keys(this.colsCache)) this._dropSnap(this.colsCache[k]);
     this.colsCache = {};
-    this.sliderCache = {};
+    this.sliderCache = {};                       // through the setter: releases the step anchors
   }
   _dropSnap(entry) { if (entry && entry[0] && entry[0].slot !== undefined) addon.snapshotDrop(this._h, entry[0].slot); }
   saveCache(id) {

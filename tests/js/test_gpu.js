@@ -19,7 +19,8 @@ function fnv(grid) {
 }
 const same = (a, b, what) => { assert.strictEqual(a.length, b.length, what + ' length'); for (let k = 0; k < a.length; k++) if (a[k] !== b[k]) assert.fail(`${what} differs at ${k}: ${a[k]} vs ${b[k]}`); };
 
-for (const name of ['vertical_small', 'stencil_small', 'stencil_odd', 'masks_small', 'growth_small', 'cavity_small', 'kcache_small', 'anchor_256']) {
+for (const name of ['vertical_small', 'stencil_small', 'stencil_odd', 'masks_small', 'growth_small', 'cavity_small', 'kcache_small', 'anchor_256',
+  'wet_ald_small', 'wet_ald_cache', 'wet_ald_thin']) {
   const c = JSON.parse(fs.readFileSync(path.join(GOLD, name + '.json')));
   const binPath = path.join(GOLD, name + '.bin.gz');
   const bin = fs.existsSync(binPath) ? zlib.gunzipSync(fs.readFileSync(binPath)) : null;
@@ -39,7 +40,17 @@ for (const name of ['vertical_small', 'stencil_small', 'stencil_odd', 'masks_sma
       case 'cmp': g.cmp(s.t, s.mat); break;
       case 'strip_connected': g.strip_connected(s.mat); break;
       case 'identify_cavity': g.identify_cavity(); break;
+      case 'etch_wet': g.etch_wet(s.mat, s.t, s.dt === undefined ? { isCache: !!s.isCache } : { isCache: !!s.isCache, dt: s.dt }); break;
+      case 'deposit_ALD': g.deposit_ALD(s.mat, s.t, s.dt === undefined ? { isCache: !!s.isCache } : { isCache: !!s.isCache, dt: s.dt }); break;
+      case 'slider_reset': g.sliderCache = {}; break;
       default: throw new Error(s.op);
+    }
+    if (s.slider) {
+      const a = g.sliderCache.aldCache, w = g.sliderCache.wetetchCache;
+      assert.deepStrictEqual(a ? Array.from(a.gridWithCavity.keys()) : [], s.slider.ald_keys, `${name} step ${idx} ALD anchors`);
+      assert.deepStrictEqual(w ? Array.from(w.grid.keys()) : [], s.slider.wet_keys, `${name} step ${idx} wet anchors`);
+      assert.strictEqual(a && a.exposedSegments ? a.exposedSegments.count : 0, s.slider.seeds, `${name} step ${idx} seeds`);
+      assert.strictEqual(w ? w.R : 0, s.slider.wet_R, `${name} step ${idx} wet R`);
     }
     assert.strictEqual(g.maxHeight(), s.max_height, `${name} step ${idx} maxHeight`);
     if (s.dump_index !== undefined) {
