@@ -158,7 +158,19 @@ def flow_c5():
     return a + b + extra
 
 
-FLOWS = {"c1": flow_c1, "c2": flow_c2, "c3": flow_c3, "c4": flow_c4, "c5": flow_c5}
+def flow_cw():
+    """Not one of the five benchmark configurations: a patterned stack taken through the reference's
+    incremental models (WETETCH undercut, ALD refill with pinch-off, STRIP, CMP) for parity at scale."""
+    return [
+        _s("SUBSTR", None, SI, 30), _s("DEPO", None, OX, 8), _s("DEPO", None, NIT, 12),
+        _s("ETCH", "M", ALL, 26), _s("WETETCH", None, OX, 5), _s("ALD", None, M6, 3),
+        _s("ETCH", "Mc", ALL, 14), _s("WETETCH", None, ALL, 2.5), _s("ALD", None, M7, 6),
+        _s("CMP", None, 0, 7), _s("STRIP", None, M6, 1), _s("DEPO", None, OX, 6, 1.0),
+        _s("WETETCH", None, M7, 3.3), _s("ALD", None, NIT, 2.2),
+    ]
+
+
+FLOWS = {"c1": flow_c1, "c2": flow_c2, "c3": flow_c3, "c4": flow_c4, "c5": flow_c5, "cw": flow_cw}
 
 
 def apply_step(grid, step, masks):
@@ -171,6 +183,14 @@ def apply_step(grid, step, masks):
         grid.deposit_general(m, step["mat"], step["t"], step["S"])
     elif step["kind"] == "ETCH":
         grid.etch_general(m, step["mat"], step["t"], step["S"])
+    elif step["kind"] == "ALD":
+        grid.deposit_ALD(step["mat"], step["t"])
+    elif step["kind"] == "WETETCH":
+        grid.etch_wet(step["mat"], step["t"])
+    elif step["kind"] == "STRIP":
+        grid.strip_connected(step["mat"])
+    elif step["kind"] == "CMP":
+        grid.cmp(step["t"], step["mat"])
     else:
         raise ValueError(step["kind"])
 

@@ -32,7 +32,7 @@ def _masks(fem, flows, g, o, specs, names, n):
     return gm, om
 
 
-@pytest.mark.parametrize("flow_name,n", [("c2", 512), ("c3", 512), ("c4", 1024), ("c5", 384)])
+@pytest.mark.parametrize("flow_name,n", [("c2", 512), ("c3", 512), ("c4", 1024), ("c5", 384), ("cw", 512)])
 def test_benchmark_flows_vs_oracle(flow_name, n):
     import fem_amd as fem
     from fem_amd import flows
@@ -42,12 +42,15 @@ def test_benchmark_flows_vs_oracle(flow_name, n):
     o = OracleGrid(2.0 * n, 2.0 * n, 2.0, 2.0)
     gm, om = _masks(fem, flows, g, o, specs, sorted({s["mask"] for s in flow if s["mask"]}), n)
     g.stats_enable(True)
+    g.keep_step_snapshots = False
     for k, s in enumerate(flow):
         flows.apply_step(g, s, gm)
         flows.apply_step(o, s, om)
+        o.slider_reset()
         assert g.checksum() == o.checksum(), f"{flow_name} step {k} {s}"
-        gs, os_ = g.stats(), o.stats()
-        assert gs[2:6] == os_[2:6], f"{flow_name} step {k} column counts {gs} vs {os_}"
+        if s["kind"] in ("SUBSTR", "DEPO", "ETCH"):
+            gs, os_ = g.stats(), o.stats()
+            assert gs[2:6] == os_[2:6], f"{flow_name} step {k} column counts {gs} vs {os_}"
         if flow_name == "c5":     # C5 extracts cross-sections after every step
             idx = [min(n - 1, 37 * q + 5) for q in range(8)]
             ln, mat, zp = o.arrays(); L = o.Lmax
