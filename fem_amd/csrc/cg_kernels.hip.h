@@ -29,6 +29,9 @@ namespace cgk {
 struct GridView {
     uint8_t*  len;
     uint32_t* rec;
+    uint32_t* top;      // split form: the top interval of every column (0 for an empty column)
+    uint16_t* topz0;    // split form: its bottom height
+    int       split;    // 1: top interval in top/topz0, planes hold intervals 0..len-2; 0: planes hold all
     size_t    N;        // columns of this handle
     int       nx, ny;
     int       lmax;     // planes provisioned
@@ -37,7 +40,9 @@ struct GridView {
     double    inv_zs;   // 1/zs, rounded once on the host
 };
 
-constexpr uint32_t REC_HOLE = 1u << 24;
+constexpr uint32_t REC_HOLE = 1u << 24;     // a vertical gap, not a layer
+constexpr uint32_t REC_MARK = 2u << 24;     // scratch bit of the flood fill (strip_connected)
+constexpr uint32_t REC_RUN  = 4u << 24;     // the nearest layer below has the same material
 __device__ __forceinline__ uint32_t rec_make(uint32_t z1q, int mat) { return (z1q & 0xffffu) | ((uint32_t)(mat & 255) << 16); }
 __device__ __forceinline__ uint32_t rec_z1(uint32_t r) { return r & 0xffffu; }
 __device__ __forceinline__ int rec_mat(uint32_t r) { return (int)((r >> 16) & 255u); }
@@ -80,62 +85,85 @@ __device__ __forceinline__ uint16_t quantz(double z, double zs, double inv_zs) {
 // ------------------------------------------------------------------------------------------
 // per-column update primitives (scalar forms; the vector forms below do the same per lane)
 // ------------------------------------------------------------------------------------------
+// All of them work on the split form of a column (GridView::split): the top interval in
+// top[c] / topz0[c], intervals 0 .. len-2 in the planes.
+
+// interval k of a column of length l, whichever form the grid is in (read-only kernels)
+__device__ __forceinline__ uint32_t col_rec(const GridView& g, size_t c, int k, int l) {
+    return (g.split && k == l - 1) ? g.top[c] : g.rec[(size_t)k * g.N + c];
+}
+
+// The column has just lost its top; l intervals remain (l >= 1).  Loads the new top from its
+// plane, drops it too if it is a gap (a gap is never on top), and looks up the new bottom.
+__device__ __forceinline__ void reload_top(const GridView& g, size_t c, int& l, uint32_t& r, unsigned& z0q) {
+    r = g.rec[(size_t)(l - 1) * g.N + c];
+    uint32_t b = l > 1 ? g.rec[(size_t)(l - 2) * g.N + c] : 0;
+    if (rec_hole(r)) {
+        l -= 1;
+        if (l == 0) { r = 0; z0q = 0; return; }
+        r = b;
+        b = l > 1 ? g.rec[(size_t)(l - 2) * g.N + c] : 0;
+    }
+    z0q = rec_z1(b);
+}
 
 // _depoAtTop_ (script_columngrid.js:397-426) for one column.  `l` is the column's current
 // length.  Returns 0 = nothing, 1 = top layer extended, 2 = layer appended, 3 = append needed
 // but no plane left (column untouched; the host grows the planes and re-runs those columns).
 __device__ __forceinline__ int depo_at_top(const GridView& g, size_t c, int l, int matId, double dz) {
     if (!(dz > 0)) return 0;
-    uint32_t r = 0;
-    size_t top = 0;
-    if (l > 0) { top = (size_t)(l - 1) * g.N + c; r = g.rec[top]; }
+    const uint32_t r = l > 0 ? g.top[c] : 0;
     const uint32_t topq = rec_z1(r);
     const uint16_t q = quantz((double)topq * g.zs + dz, g.zs, g.inv_zs);
-    if (l > 0 && rec_mat(r) == matId) { g.rec[top] = rec_with_z1(r, q); return 1; }
+    if (l > 0 && rec_mat(r) == matId) { g.top[c] = rec_with_z1(r, q); return 1; }
     if (l >= g.lmax) return 3;
-    g.rec[(size_t)l * g.N + c] = rec_make(q, matId);
+    if (l > 0) g.rec[(size_t)(l - 1) * g.N + c] = r;           // the old top takes its place in the stack
+    g.top[c] = rec_make(q, matId);                             // another material below: RUN stays clear
+    g.topz0[c] = (uint16_t)topq;
     g.len[c] = (uint8_t)(l + 1);
     return 2;
+}
+
+// One round of _applyEtchAt's loop (script_columngrid.js:565-588) on a column held in
+// registers: top record r, its bottom z0q, length l, thickness still to remove.
+// Returns 0 = the loop is over, 1 = a whole layer went and the new top must be loaded.
+__device__ __forceinline__ int etch_round(const GridView& g, uint32_t& r, unsigned z0q, int& l, double& remaining, int matId, bool isAll,
+                                          bool& touched, int& removed) {
+    if (!(remaining > CG_EPS) || l <= 0) return 0;
+    if (!isAll && rec_mat(r) != matId) return 0;
+    const double z1 = (double)rec_z1(r) * g.zs, z0 = (double)z0q * g.zs, thick = z1 - z0;
+    touched = true;
+    if (remaining < thick - CG_EPS) { r = rec_with_z1(r, quantz(z1 - remaining, g.zs, g.inv_zs)); remaining = 0; return 0; }
+    remaining -= thick; l -= 1; removed++;
+    return 1;
 }
 
 // _applyEtchAt (script_columngrid.js:553-589).  Returns number of whole layers removed in the
 // low 16 bits and 0x10000 if the column was touched at all.
 __device__ __forceinline__ int apply_etch_at(const GridView& g, size_t c, int l, int matId, double dz, bool isAll) {
-    if (!(dz > 0)) return 0;
+    if (!(dz > 0) || l <= 0) return 0;
     double remaining = dz;
-    int removed = 0, touched = 0;
+    int removed = 0; bool touched = false;
     const int l0 = l;
-    uint32_t r = l > 0 ? g.rec[(size_t)(l - 1) * g.N + c] : 0;
-    while (remaining > CG_EPS && l > 0) {
-        if (!isAll && rec_mat(r) != matId) break;
-        const uint32_t below = l > 1 ? g.rec[(size_t)(l - 2) * g.N + c] : 0;
-        const double z1 = (double)rec_z1(r) * g.zs, z0 = (double)rec_z1(below) * g.zs;
-        const double thick = z1 - z0;
-        touched = 0x10000;
-        if (remaining < thick - CG_EPS) {
-            g.rec[(size_t)(l - 1) * g.N + c] = rec_with_z1(r, quantz(z1 - remaining, g.zs, g.inv_zs));
-            remaining = 0;
-        } else {
-            remaining -= thick;
-            g.rec[(size_t)(l - 1) * g.N + c] = 0;          // removed slots are cleared (cg1:584-586)
-            l -= 1; removed++;
-            r = below;
-            if (l > 0 && rec_hole(r)) {                    // a gap under the removed layer goes with it
-                g.rec[(size_t)(l - 1) * g.N + c] = 0;
-                l -= 1;
-                r = l > 0 ? g.rec[(size_t)(l - 1) * g.N + c] : 0;
-            }
-        }
+    uint32_t r = g.top[c]; unsigned z0q = g.topz0[c];
+    while (etch_round(g, r, z0q, l, remaining, matId, isAll, touched, removed)) {
+        if (l > 0) reload_top(g, c, l, r, z0q); else { r = 0; z0q = 0; }
     }
-    if (l != l0) g.len[c] = (uint8_t)l;
-    return touched | removed;
+    if (touched) {
+        g.top[c] = r;
+        if (l != l0) { g.topz0[c] = (uint16_t)z0q; g.len[c] = (uint8_t)l; }
+    }
+    return (touched ? 0x10000 : 0) | removed;
 }
 
-// bottom of the top run of matId (script_columngrid.js:646-660); the top layer is known to be
-// matId.  Gaps do not interrupt the run (the reference only compares materials).
-__device__ __forceinline__ double floor_of_top_run(const GridView& g, size_t c, int l, int matId, unsigned& scanned) {
-    int s = l - 1;                 // interval whose bottom is the current floor
+// bottom of the top run of matId (script_columngrid.js:646-660); the top layer (record r, bottom
+// z0q) is known to be matId.  Gaps do not interrupt the run (the reference only compares
+// materials).  The RUN flag of a record says that the nearest layer below it has the same
+// material, so the usual case -- the run is the top layer alone -- needs no look at the stack.
+__device__ __forceinline__ double floor_of_top_run(const GridView& g, size_t c, int l, int matId, uint32_t r, unsigned z0q, unsigned& scanned) {
     scanned++;
+    if (!(r & REC_RUN)) return (double)z0q * g.zs;
+    int s = l - 1;                 // interval whose bottom is the current floor
     while (s > 0) {
         uint32_t b = g.rec[(size_t)(s - 1) * g.N + c];
         int nb = s - 1;
@@ -188,7 +216,7 @@ __global__ __launch_bounds__(256) void k_vertical_1(GridView g, const uint8_t* _
         } else {
             if (only_len >= 0) {
                 if (l != only_len) continue;
-                if (l > 0 && rec_mat(g.rec[(size_t)(l - 1) * g.N + c]) == matId) continue;
+                if (l > 0 && rec_mat(g.top[c]) == matId) continue;
             }
             const int r = depo_at_top(g, c, l, matId, t);
             if (r == 3) flags[0] = 1;
@@ -204,11 +232,11 @@ __global__ __launch_bounds__(256) void k_vertical_1(GridView g, const uint8_t* _
 // ------------------------------------------------------------------------------------------
 // 4 columns per thread ("groups")
 // ------------------------------------------------------------------------------------------
-// A thread owns 4 consecutive columns: len and mask move as one dword, a plane's records as
-// one 16-byte vector.  Neighbouring columns usually have the same number of layers, so their
-// tops share a plane.  Columns of a group with differing lengths are handled length by
-// length; every store is a whole vector in which the lanes of the other columns carry the
-// values just loaded (the thread owns all 4 columns, nobody else writes them).  N % 4 == 0.
+// A thread owns 4 consecutive columns: len and mask move as one dword, the 4 top records as one
+// 16-byte vector, their bottoms as one 8-byte vector -- four streams whose addresses do not
+// depend on the column lengths.  Only an append (old top -> its plane) and the removal of a
+// whole layer (new top <- its plane) touch the planes; columns of a group that do so at the
+// same length share one 16-byte access.  N % 4 == 0.
 typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -219,133 +247,108 @@ __device__ __forceinline__ u8x4 ld_u8x4(const uint8_t* p) { return *(const u8x4*
 __device__ __forceinline__ void st_u8x4(uint8_t* p, u8x4 v) { *(u8x4*)p = v; }
 __device__ __forceinline__ u32x4 ld_rec4(const uint32_t* p) { return *(const u32x4*)p; }
 __device__ __forceinline__ void st_rec4(uint32_t* p, u32x4 v) { *(u32x4*)p = v; }
+__device__ __forceinline__ u16x4 ld_u16x4(const uint16_t* p) { return *(const u16x4*)p; }
+__device__ __forceinline__ void st_u16x4(uint16_t* p, u16x4 v) { *(u16x4*)p = v; }
 __device__ __forceinline__ unsigned open_bits(u8x4 mk) { return (mk[0] ? 1u : 0u) | (mk[1] ? 2u : 0u) | (mk[2] ? 4u : 0u) | (mk[3] ? 8u : 0u); }
-__device__ __forceinline__ int first_open_len(unsigned open, u8x4 ln) {
-    return (open & 1) ? ln[0] : (open & 2) ? ln[1] : (open & 4) ? ln[2] : ln[3];
-}
 
-// top plane of a group, loaded ahead of time for the length of its first open column
-struct Pre4 { int l; bool have_below; u32x4 top, below; };   // below: plane l-2, loaded too when have_below
-
-// _depoAtTop_ on the open columns of a group: column j grows by dz[j] (> 0).
+// _depoAtTop_ on the open columns of a group: column j grows by dz[j] (> 0).  tv = the 4 tops.
 template <bool STATS>
 __device__ __forceinline__ void depo_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
-                                            const Pre4& pre, int* __restrict__ flags, unsigned& n_ext, unsigned& n_app) {
-    u8x4 nl = ln; bool len_dirty = false;
-    const int lj[4] = {ln[0], ln[1], ln[2], ln[3]};
-    const int lmax_all = max(max(lj[0], lj[1]), max(lj[2], lj[3]));
-    unsigned rem = open;
-    while (rem) {
-        const int l = first_open_len(rem, ln);
-        unsigned sel = 0;
+                                            u32x4 tv, int* __restrict__ flags, unsigned& n_ext, unsigned& n_app) {
+    u32x4 nv = tv; u8x4 nl = ln;
+    unsigned ext = 0, app = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (((rem >> j) & 1) && lj[j] == l) sel |= 1u << j;
-        rem &= ~sel;
-        u32x4 tv = (u32x4)(0);
-        size_t top = 0;
-        if (l > 0) { top = (size_t)(l - 1) * g.N + c0; tv = (pre.l == l) ? pre.top : ld_rec4(g.rec + top); }
-        unsigned ext = 0;
-        uint32_t q[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (!((sel >> j) & 1)) continue;
-            q[j] = quantz((double)rec_z1(tv[j]) * g.zs + dz[j], g.zs, g.inv_zs);
-            if (l > 0 && rec_mat(tv[j]) == matId) ext |= 1u << j;
-        }
-        const unsigned app = sel & ~ext;
-        if (ext) {
-            u32x4 nv = tv;
-#pragma unroll
-            for (int j = 0; j < 4; j++) if ((ext >> j) & 1) nv[j] = rec_with_z1(tv[j], q[j]);
-            st_rec4(g.rec + top, nv);
-            if (STATS) n_ext += __popc(ext);
-        }
-        if (app) {
-            if (l >= g.lmax) flags[0] = 1;      // no plane left: the host grows the planes and re-runs these columns
-            else {
-                const size_t b = (size_t)l * g.N + c0;
-                u32x4 av = (u32x4)(0);
-                if (lmax_all > l) av = ld_rec4(g.rec + b);       // a taller neighbour lives in this plane
-#pragma unroll
-                for (int j = 0; j < 4; j++) if ((app >> j) & 1) { av[j] = rec_make(q[j], matId); nl[j] = (uint8_t)(l + 1); }
-                st_rec4(g.rec + b, av);
-                len_dirty = true;
-                if (STATS) n_app += __popc(app);
-            }
-        }
+    for (int j = 0; j < 4; j++) {
+        if (!((open >> j) & 1)) continue;
+        const int l = ln[j];
+        const uint32_t r = l > 0 ? tv[j] : 0;
+        const uint32_t q = quantz((double)rec_z1(r) * g.zs + dz[j], g.zs, g.inv_zs);
+        if (l > 0 && rec_mat(r) == matId) { nv[j] = rec_with_z1(r, q); ext |= 1u << j; }
+        else if (l >= g.lmax) flags[0] = 1;      // no plane left: the host grows the planes and re-runs these columns
+        else { nv[j] = rec_make(q, matId); nl[j] = (uint8_t)(l + 1); app |= 1u << j; }
     }
-    if (len_dirty) st_u8x4(g.len + c0, nl);
+    if (!(ext | app)) return;
+    if (app) {
+        // the old tops move into the stack
+        const int l0 = ln[0];
+        if (app == 15u && as_u32(ln) == as_u32(splat4(l0))) { if (l0 > 0) st_rec4(g.rec + (size_t)(l0 - 1) * g.N + c0, tv); }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (((app >> j) & 1) && ln[j] > 0) g.rec[(size_t)(ln[j] - 1) * g.N + c0 + j] = tv[j];
+        }
+        u16x4 z;
+        if (app == 15u) { z[0] = (unsigned short)rec_z1(ln[0] ? tv[0] : 0); z[1] = (unsigned short)rec_z1(ln[1] ? tv[1] : 0);
+                          z[2] = (unsigned short)rec_z1(ln[2] ? tv[2] : 0); z[3] = (unsigned short)rec_z1(ln[3] ? tv[3] : 0); }
+        else {
+            z = ld_u16x4(g.topz0 + c0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) if ((app >> j) & 1) z[j] = (unsigned short)rec_z1(ln[j] ? tv[j] : 0);
+        }
+        st_u16x4(g.topz0 + c0, z);
+        st_u8x4(g.len + c0, nl);
+        if (STATS) n_app += __popc(app);
+    }
+    st_rec4(g.top + c0, nv);
+    if (STATS) n_ext += __popc(ext);
 }
 
 // _applyEtchAt on the open columns of a group: column j loses dz[j] (> 0) from the top.
-// Columns of equal length stay in lockstep: every pass takes exactly one layer off those that
-// keep going.  A column that uncovers a gap leaves the lockstep and finishes on its own.
+// tv / zv = the 4 tops and their bottoms.  A column that loses its whole top layer reloads the
+// next one from the planes; columns doing so at the same length share the vector loads.
 template <bool STATS>
 __device__ __forceinline__ void etch_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
-                                            bool isAll, const Pre4& pre, unsigned& n_touched, unsigned& n_removed) {
-    u8x4 nl = ln; bool len_dirty = false;
-    const int lj[4] = {ln[0], ln[1], ln[2], ln[3]};
-    unsigned rem = open, touched = 0, solo = 0;
-    double solo_r[4] = {0, 0, 0, 0};
-    bool first = true;
-    while (rem) {
-        const int l = first_open_len(rem, ln);
-        unsigned active = 0;
+                                            bool isAll, u32x4 tv, u16x4 zv, unsigned& n_touched, unsigned& n_removed) {
+    int l[4] = {ln[0], ln[1], ln[2], ln[3]};
+    uint32_t r[4] = {tv[0], tv[1], tv[2], tv[3]};
+    unsigned z0[4] = {zv[0], zv[1], zv[2], zv[3]};
+    double rem[4] = {dz[0], dz[1], dz[2], dz[3]};
+    unsigned need = 0, dirty = 0, popped = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (((rem >> j) & 1) && lj[j] == l) active |= 1u << j;
-        rem &= ~active;
-        double r[4] = {dz[0], dz[1], dz[2], dz[3]};
-        u32x4 tv = (u32x4)(0);
-        const bool use_pre = first && pre.l == l;
-        if (l > 0) tv = use_pre ? pre.top : ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0);
-        first = false;
-        for (int cur = l; active && cur > 0; cur--) {
-            // which active columns does this layer concern at all?
-            unsigned hit = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) if (((active >> j) & 1) && r[j] > CG_EPS && (isAll || rec_mat(tv[j]) == matId)) hit |= 1u << j;
-            if (!hit) break;
-            u32x4 bv = (u32x4)(0);
-            if (cur > 1) bv = (use_pre && pre.have_below && cur == l) ? pre.below : ld_rec4(g.rec + (size_t)(cur - 2) * g.N + c0);
-            u32x4 nv = tv;
-            unsigned next = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (!((hit >> j) & 1)) continue;
-                const double z1 = (double)rec_z1(tv[j]) * g.zs, z0 = (double)rec_z1(bv[j]) * g.zs, thick = z1 - z0;
-                touched |= 1u << j;
-                if (r[j] < thick - CG_EPS) { nv[j] = rec_with_z1(tv[j], quantz(z1 - r[j], g.zs, g.inv_zs)); r[j] = 0; }
-                else {
-                    r[j] -= thick; nv[j] = 0;                       // removed slots are cleared (cg1:584-586)
-                    nl[j] = (uint8_t)(cur - 1); len_dirty = true;
-                    if (STATS) n_removed++;
-                    if (cur > 1 && rec_hole(bv[j])) { solo |= 1u << j; solo_r[j] = r[j]; }   // gap uncovered
-                    else next |= 1u << j;
-                }
-            }
-            st_rec4(g.rec + (size_t)(cur - 1) * g.N + c0, nv);
-            active = next;
-            tv = bv;
-        }
+    for (int j = 0; j < 4; j++) {
+        if (!((open >> j) & 1) || l[j] <= 0) continue;
+        bool t = false; int rm = 0;
+        if (etch_round(g, r[j], z0[j], l[j], rem[j], matId, isAll, t, rm)) { popped |= 1u << j; if (l[j] > 0) need |= 1u << j; else { r[j] = 0; z0[j] = 0; } }
+        if (t) dirty |= 1u << j;
+        if (STATS) n_removed += rm;
     }
-    if (len_dirty) st_u8x4(g.len + c0, nl);
-    if (solo) {
+    while (need) {
+        const int j0 = __ffs(need) - 1;
+        const int L = l[j0];                                   // intervals left; the new top is interval L-1
+        unsigned sel = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (((need >> j) & 1) && l[j] == L) sel |= 1u << j;
+        need &= ~sel;
+        const u32x4 A = ld_rec4(g.rec + (size_t)(L - 1) * g.N + c0);
+        const u32x4 B = L > 1 ? ld_rec4(g.rec + (size_t)(L - 2) * g.N + c0) : (u32x4)(0);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (!((solo >> j) & 1)) continue;
-            int l = nl[j];                                          // the hole is the top interval now
-            g.rec[(size_t)(l - 1) * g.N + c0 + j] = 0; l -= 1;
-            g.len[c0 + j] = (uint8_t)l;
-            const int rr = apply_etch_at(g, c0 + j, l, matId, solo_r[j], isAll);
-            if (STATS) n_removed += (rr & 0xffff);
+            if (!((sel >> j) & 1)) continue;
+            r[j] = A[j]; z0[j] = rec_z1(B[j]);
+            if (rec_hole(A[j])) {                              // a gap under the removed layer goes with it
+                l[j] = L - 1;
+                if (l[j] > 0) { r[j] = B[j]; z0[j] = l[j] > 1 ? rec_z1(g.rec[(size_t)(l[j] - 2) * g.N + c0 + j]) : 0; }
+                else { r[j] = 0; z0[j] = 0; }
+            }
+            bool t = false; int rm = 0;
+            if (etch_round(g, r[j], z0[j], l[j], rem[j], matId, isAll, t, rm)) { if (l[j] > 0) need |= 1u << j; else { r[j] = 0; z0[j] = 0; } }
+            if (STATS) n_removed += rm;
         }
     }
-    if (STATS) n_touched += __popc(touched);
+    if (dirty) {
+        u32x4 nv; nv[0] = r[0]; nv[1] = r[1]; nv[2] = r[2]; nv[3] = r[3];
+        st_rec4(g.top + c0, nv);
+        if (popped) {
+            u16x4 nz; nz[0] = (unsigned short)z0[0]; nz[1] = (unsigned short)z0[1]; nz[2] = (unsigned short)z0[2]; nz[3] = (unsigned short)z0[3];
+            u8x4 nl; nl[0] = (uint8_t)l[0]; nl[1] = (uint8_t)l[1]; nl[2] = (uint8_t)l[2]; nl[3] = (uint8_t)l[3];
+            st_u16x4(g.topz0 + c0, nz);
+            st_u8x4(g.len + c0, nl);
+        }
+    }
+    if (STATS) n_touched += __popc(dirty);
 }
 
 // Vertical deposit / etch (fast paths, cg1:445-454 and 609-618).  A thread owns U groups that
-// are 256 groups apart; the U len/mask words are loaded together, then the U top planes, and
-// only then anything is computed or stored: U dependent-load chains in flight per thread.
+// are 256 groups apart; all their loads are issued before anything is computed or stored.
 template <bool ETCH, bool STATS, int U>
 __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
                                                      int* __restrict__ flags, unsigned long long* gstats) {
@@ -364,26 +367,19 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
         const size_t tile = sweep * gridDim.x + (blockIdx.x + sweep) % gridDim.x;
         if (tile >= ntiles) continue;
         const size_t gbase = tile * tile_groups + threadIdx.x;
-        u8x4 ln[U]; unsigned open[U]; Pre4 pre[U];
+        u8x4 ln[U]; unsigned open[U]; u32x4 tv[U]; u16x4 zv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t gi = gbase + (size_t)u * 256;
-            open[u] = 0; ln[u] = splat4(0);
+            open[u] = 0; ln[u] = splat4(0); tv[u] = (u32x4)(0); zv[u] = (u16x4)(0);
             if (gi < ngroups) {
                 const size_t c0 = gi << 2;
                 open[u] = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
-                ln[u] = ld_u8x4(g.len + c0);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            pre[u].l = -1; pre[u].have_below = false;
-            if (!open[u]) continue;
-            const int l = first_open_len(open[u], ln[u]);
-            if (l > 0) {
-                const size_t c0 = (gbase + (size_t)u * 256) << 2;
-                pre[u].l = l; pre[u].top = ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0);
-                if (ETCH && l > 1) { pre[u].have_below = true; pre[u].below = ld_rec4(g.rec + (size_t)(l - 2) * g.N + c0); }
+                if (open[u]) {
+                    ln[u] = ld_u8x4(g.len + c0);
+                    tv[u] = ld_rec4(g.top + c0);
+                    if (ETCH) zv[u] = ld_u16x4(g.topz0 + c0);
+                }
             }
         }
 #pragma unroll
@@ -391,12 +387,8 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
             if (!open[u]) continue;
             const size_t c0 = (gbase + (size_t)u * 256) << 2;
             if (STATS) loc[0] += __popc(open[u]);
-            if (ETCH) {
-                unsigned o = 0;                                      // empty columns have nothing to etch
-#pragma unroll
-                for (int j = 0; j < 4; j++) if (((open[u] >> j) & 1) && ln[u][j] > 0) o |= 1u << j;
-                if (o) etch_group4<STATS>(g, c0, o, ln[u], dz, matId, isAll, pre[u], loc[1], loc[2]);
-            } else depo_group4<STATS>(g, c0, open[u], ln[u], dz, matId, pre[u], flags, loc[1], loc[2]);
+            if (ETCH) etch_group4<STATS>(g, c0, open[u], ln[u], dz, matId, isAll, tv[u], zv[u], loc[1], loc[2]);
+            else depo_group4<STATS>(g, c0, open[u], ln[u], dz, matId, tv[u], flags, loc[1], loc[2]);
         }
     }
     if (STATS) {
@@ -422,7 +414,7 @@ __global__ __launch_bounds__(256) void k_snapshot_tops(GridView g, const uint8_t
     const size_t off = (size_t)R * g.ny;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
-        const uint32_t r = l > 0 ? g.rec[(size_t)(l - 1) * g.N + c] : 0;
+        const uint32_t r = l > 0 ? g.top[c] : 0;
         topq[off + c] = (uint16_t)rec_z1(r);
         if (ETCH) eflag[off + c] = ((!mask || mask[c]) && l > 0 && (isAll || rec_mat(r) == matId)) ? 1 : 0;
     }
@@ -438,16 +430,10 @@ __global__ __launch_bounds__(256) void k_snapshot_tops_g4(GridView g, const uint
     for (size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += stride) {
         const size_t c0 = gi << 2;
         const u8x4 ln = ld_u8x4(g.len + c0);
-        const int l = ln[0];
-        u32x4 tv = (u32x4)(0);
-        if (as_u32(ln) == as_u32(splat4(l))) { if (l > 0) tv = ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0); }
-        else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) { const int lj = ln[j]; if (lj > 0) tv[j] = g.rec[(size_t)(lj - 1) * g.N + c0 + j]; }
-        }
+        const u32x4 tv = ld_rec4(g.top + c0);
         u16x4 q;
 #pragma unroll
-        for (int j = 0; j < 4; j++) q[j] = (unsigned short)rec_z1(tv[j]);
+        for (int j = 0; j < 4; j++) q[j] = ln[j] ? (unsigned short)rec_z1(tv[j]) : (unsigned short)0;
         *(u16x4*)(topq + off + c0) = q;
         if (ETCH) {
             const u8x4 mk = mask ? ld_u8x4(mask + c0) : splat4(1);
@@ -615,7 +601,7 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 int l = g.len[c];
                 if (ETCH) {
                     float F = 0.f;
-                    if (!isAll && l > 0) F = (float)fmax(0.0, floor_of_top_run(g, c, l, matId, loc[3]));
+                    if (!isAll && l > 0) F = (float)fmax(0.0, floor_of_top_run(g, c, l, matId, g.top[c], g.topz0[c], loc[3]));
                     float hp = fmaxf(0.f, fmaxf(F, m[r]));             // cg1:725
                     double dz = (double)own[r] - (double)hp;
                     if (dz > CG_EPS) {
@@ -626,7 +612,7 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 } else {
                     if (only_len >= 0) {
                         if (l != only_len) continue;
-                        if (l > 0 && rec_mat(g.rec[(size_t)(l - 1) * g.N + c]) == matId) continue;
+                        if (l > 0 && rec_mat(g.top[c]) == matId) continue;
                     }
                     double dz = (double)m[r] - (double)own[r];         // cg1:534-536
                     if (STATS) loc[0]++;
@@ -783,9 +769,9 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
 #undef CG_ADD
             // ---- per-column update
             const u8x4 ln = ld_u8x4(g.len + c0);
+            const u32x4 tv = ld_rec4(g.top + c0);
             double dz[4] = {0, 0, 0, 0};
             unsigned open = 0;
-            Pre4 pre; pre.l = -1; pre.have_below = false;
             if (STATS) loc[0] += __popc(act);
             if (!ETCH) {
 #pragma unroll
@@ -794,36 +780,21 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                     const double d = (double)m[c] - (double)own[c];          // cg1:534-537
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) depo_group4<STATS>(g, c0, open, ln, dz, matId, pre, flags, loc[1], loc[2]);
+                if (open) depo_group4<STATS>(g, c0, open, ln, dz, matId, tv, flags, loc[1], loc[2]);
             } else {
                 const bool isAll = (matId == 255);
-                float F[4] = {0.f, 0.f, 0.f, 0.f};
-                const int l = ln[0];
-                const bool uniform = as_u32(ln) == as_u32(splat4(l));
-                if (uniform && l > 0) { pre.l = l; pre.top = ld_rec4(g.rec + (size_t)(l - 1) * g.N + c0); }
-                if (!isAll) {
-                    // floor = bottom of the top run of matId (cg1:646-660)
-                    u32x4 below = (u32x4)(0);
-                    if (uniform && l >= 2) { below = ld_rec4(g.rec + (size_t)(l - 2) * g.N + c0); pre.have_below = true; pre.below = below; }
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        if (!((act >> c) & 1)) continue;
-                        double floorZ;
-                        if (uniform && (l < 2 || (!rec_hole(below[c]) && rec_mat(below[c]) != matId))) {
-                            floorZ = (double)rec_z1(below[c]) * g.zs;         // the usual case: the run is the top layer alone
-                            if (STATS) loc[3]++;
-                        } else floorZ = floor_of_top_run(g, c0 + c, ln[c], matId, loc[3]);
-                        F[c] = (float)fmax(0.0, floorZ);
-                    }
-                }
+                const u16x4 zv = ld_u16x4(g.topz0 + c0);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     if (!((act >> c) & 1)) continue;
-                    const float hpv = fmaxf(0.f, fmaxf(F[c], m[c]));                  // cg1:725
+                    // floor = bottom of the top run of matId (cg1:646-660)
+                    float F = 0.f;
+                    if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, ln[c], matId, tv[c], zv[c], loc[3]));
+                    const float hpv = fmaxf(0.f, fmaxf(F, m[c]));                     // cg1:725
                     const double d = (double)own[c] - (double)hpv;
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) etch_group4<STATS>(g, c0, open, ln, dz, matId, isAll, pre, loc[1], loc[2]);
+                if (open) etch_group4<STATS>(g, c0, open, ln, dz, matId, isAll, tv, zv, loc[1], loc[2]);
             }
         }
     }
@@ -897,7 +868,7 @@ __global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restric
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         int l = g.len[c];
-        if (l > 0) { unsigned q = rec_z1(g.rec[(size_t)(l - 1) * g.N + c]); mq = q > mq ? q : mq; ml = (unsigned)l > ml ? (unsigned)l : ml; }
+        if (l > 0) { unsigned q = rec_z1(col_rec(g, c, l - 1, l)); mq = q > mq ? q : mq; ml = (unsigned)l > ml ? (unsigned)l : ml; }
     }
     for (int o = 32; o > 0; o >>= 1) {
         unsigned a = __shfl_down(mq, o, 64), b = __shfl_down(ml, o, 64);
@@ -922,12 +893,12 @@ __global__ __launch_bounds__(256) void k_checksum(GridView g, unsigned long long
         unsigned long long gc = (unsigned long long)g.i0 * g.ny + c;
         const int l = min((int)g.len[c], g.lmax);
         int layers = 0;
-        for (int k = 0; k < l; k++) layers += !rec_hole(g.rec[(size_t)k * g.N + c]);
+        for (int k = 0; k < l; k++) layers += !rec_hole(col_rec(g, c, k, l));
         unsigned long long h = splitmix64(gc);
         h = splitmix64(h ^ (unsigned long long)layers);
         unsigned prev = 0;
         for (int k = 0; k < l; k++) {
-            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            const uint32_t r = col_rec(g, c, k, l);
             if (!rec_hole(r)) {
                 unsigned long long v = (unsigned long long)rec_mat(r) | ((unsigned long long)prev << 8) | ((unsigned long long)rec_z1(r) << 24);
                 h = splitmix64(h ^ v);
@@ -1004,8 +975,6 @@ __global__ __launch_bounds__(256) void k_cmp_apply(GridView g, double targetZ, i
 // overlap".  The mark lives in the record's flag byte.  All height tests are done on the
 // quantised integers: the reference's eps (1e-9 nm) is far below one step, so
 // a < b - eps on de-quantised values is a < b on the integers.
-constexpr uint32_t REC_MARK = 2u << 24;
-
 __device__ __forceinline__ unsigned z0_of(const GridView& g, size_t c, int k) { return k > 0 ? rec_z1(g.rec[(size_t)(k - 1) * g.N + c]) : 0u; }
 
 // isExposed (cg1:882-905) for layer [z0q, z1q] of column (i, j)
@@ -1144,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_gather_columns(GridView g, size_t col0,
         const int l = min((int)g.len[c], g.lmax);
         int w = 0; unsigned prev = 0;
         for (int k = 0; k < l; k++) {
-            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            const uint32_t r = col_rec(g, c, k, l);
             if (!rec_hole(r) && w < L) {
                 const size_t o = s * (size_t)L + w;
                 omat[o] = (uint8_t)rec_mat(r); ozp[2 * o] = (uint16_t)prev; ozp[2 * o + 1] = (uint16_t)rec_z1(r);
@@ -1183,6 +1152,38 @@ __global__ __launch_bounds__(256) void k_scatter_columns(GridView g, size_t col0
         if (w > g.lmax) atomicMax(&flags[3], w);
         g.len[c] = (uint8_t)min(w, g.lmax);
         for (int k = min(w, g.lmax); k < g.lmax; k++) g.rec[(size_t)k * g.N + c] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the two forms of a column
+// ------------------------------------------------------------------------------------------
+// split -> whole: the top interval takes its place in the planes
+__global__ __launch_bounds__(256) void k_demote(GridView g) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const int l = g.len[c];
+        if (l > 0) g.rec[(size_t)(l - 1) * g.N + c] = g.top[c];
+    }
+}
+
+// whole -> split: top / topz0 from the planes, and the RUN flag of every interval brought up to
+// date (the kernels that restructure columns do not maintain it)
+__global__ __launch_bounds__(256) void k_promote(GridView g) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const int l = g.len[c];
+        int below_mat = -1; unsigned prev = 0, z0 = 0; uint32_t r = 0;
+        for (int k = 0; k < l; k++) {
+            r = g.rec[(size_t)k * g.N + c];
+            z0 = prev; prev = rec_z1(r);
+            if (rec_hole(r)) continue;
+            const uint32_t want = (r & ~REC_RUN) | ((below_mat == rec_mat(r)) ? REC_RUN : 0u);
+            if (want != r) { r = want; g.rec[(size_t)k * g.N + c] = r; }
+            below_mat = rec_mat(r);
+        }
+        g.top[c] = l > 0 ? r : 0;
+        g.topz0[c] = (uint16_t)(l > 0 ? z0 : 0);
     }
 }
 

@@ -54,7 +54,8 @@ struct ConfKernel {
 };
 
 struct Snapshot {
-    uint8_t* len = nullptr; uint32_t* rec = nullptr;
+    uint8_t* len = nullptr; uint32_t* rec = nullptr; uint32_t* top = nullptr; uint16_t* topz0 = nullptr;
+    bool split = true;
     int lmax = 0; int len_bound = 0; bool has_gaps = false, has_cavity = false;
 };
 
@@ -75,6 +76,8 @@ struct cg_grid {
     double dx = 0, dy = 0, zscale = 0.1;
     int lmax = 32;
     uint8_t* len = nullptr; uint32_t* rec = nullptr;      // see cg_kernels.hip.h for the layout
+    uint32_t* top = nullptr; uint16_t* topz0 = nullptr;   // split form: top interval of every column and its bottom
+    bool split = true;                                    // which form the columns are in right now
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<uint8_t*> masks;
     std::deque<ConfKernel*> kcache;
@@ -164,7 +167,7 @@ int js_to_int32(double v) {                  // (v | 0)
 
 GridView view(const cg_grid* g) {
     GridView v;
-    v.len = g->len; v.rec = g->rec;
+    v.len = g->len; v.rec = g->rec; v.top = g->top; v.topz0 = g->topz0; v.split = g->split ? 1 : 0;
     v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
     return v;
 }
@@ -177,7 +180,9 @@ unsigned blocks_for(size_t n) {
 void free_planes(cg_grid* g) {
     if (g->len) (void)hipFree(g->len);
     if (g->rec) (void)hipFree(g->rec);
-    g->len = nullptr; g->rec = nullptr;
+    if (g->top) (void)hipFree(g->top);
+    if (g->topz0) (void)hipFree(g->topz0);
+    g->len = nullptr; g->rec = nullptr; g->top = nullptr; g->topz0 = nullptr;
 }
 
 int alloc_planes(cg_grid* g, int lmax) {
@@ -185,21 +190,41 @@ int alloc_planes(cg_grid* g, int lmax) {
     size_t S = g->N * (size_t)lmax;
     HIPCHK(g, hipMalloc(&g->len, std::max<size_t>(g->N, 4)));
     HIPCHK(g, hipMalloc(&g->rec, std::max<size_t>(4 * S, 4)));
+    HIPCHK(g, hipMalloc(&g->top, std::max<size_t>(4 * g->N, 16)));
+    HIPCHK(g, hipMalloc(&g->topz0, std::max<size_t>(2 * g->N, 16)));
     g->lmax = lmax;
     return CG_OK;
 }
 
-// Empty every column.  Slots at or above a column's length are zero by invariant (removed
-// layers are cleared), so only the planes below the host-tracked bound of max(len) can hold
-// anything; `all` forces every plane (fresh allocations).
+// Empty every column.  Only len / top / topz0 are cleared: plane slots at or above a column's
+// length hold unspecified data and nothing reads them.
 int zero_planes(cg_grid* g, bool all = true) {
+    (void)all;
     ProfScope ps(g, CG_K_CLEAR);
-    const int planes = all ? g->lmax : std::min(g->lmax, std::max(0, g->len_bound));
-    size_t S = g->N * (size_t)planes;
     HIPCHK(g, hipMemsetAsync(g->len, 0, g->N, g->stream));
-    if (S == 0) { g->len_bound = 0; g->has_gaps = false; g->has_cavity = false; return CG_OK; }
-    HIPCHK(g, hipMemsetAsync(g->rec, 0, 4 * S, g->stream));
+    HIPCHK(g, hipMemsetAsync(g->top, 0, 4 * g->N, g->stream));
+    HIPCHK(g, hipMemsetAsync(g->topz0, 0, 2 * g->N, g->stream));
+    g->split = true;
     g->len_bound = 0; g->has_gaps = false; g->has_cavity = false;
+    return CG_OK;
+}
+
+// The kernels of the vertical and lateral steps work on the split form, the ones that
+// restructure whole columns (strip, cavity, CMP, wet etch, ALD, upload) on whole stacks.
+int ensure_split(cg_grid* g) {
+    if (g->split) return CG_OK;
+    ProfScope ps(g, CG_K_OTHER);
+    hipLaunchKernelGGL(k_promote, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g));
+    HIPCHK(g, hipGetLastError());
+    g->split = true;
+    return CG_OK;
+}
+int ensure_whole(cg_grid* g) {
+    if (!g->split) return CG_OK;
+    ProfScope ps(g, CG_K_OTHER);
+    hipLaunchKernelGGL(k_demote, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g));
+    HIPCHK(g, hipGetLastError());
+    g->split = false;
     return CG_OK;
 }
 
@@ -471,6 +496,7 @@ GridView alt_view(const cg_grid* g, int which) {
 
 void swap_alt(cg_grid* g, int which) {
     std::swap(g->len, g->alt_len[which]); std::swap(g->rec, g->alt_rec[which]); std::swap(g->lmax, g->alt_lmax[which]);
+    g->split = false;                            // the out-of-place kernels write whole stacks
 }
 
 // Run `launch(dst)` with dst = spare planes `which`, grow and repeat while a column does not
@@ -548,7 +574,8 @@ int build_ald_taps(const cg_grid* g, double t, std::vector<AldTap>* taps) {
 int ald_coat(cg_grid* g, int mat, double t) {
     if (!g->has_seeds) return fail(g, CG_ERR_STATE, "deposit_ALD: no seeds held (cg_ald_collect_seeds first)");
     unsigned qtop = 0;
-    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    int rc = ensure_whole(g); if (rc) return rc;
+    rc = refresh_len_bound(g, &qtop); if (rc) return rc;
     const double Hnow = qtop > 0 ? (double)qtop * g->zscale : 1.0;                               // maxHeight()
     const double Hcap = Hnow + t + g->zscale;                                                    // cg2:501, 702
     const AldLayout L = make_bit_layout(g, Hcap);
@@ -652,7 +679,7 @@ int cg_destroy(cg_grid* g) {
     free_planes(g);
     for (auto m : g->masks) if (m) (void)hipFree(m);
     for (auto k : g->kcache) free_kernel(k);
-    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.rec); }
+    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.rec); (void)hipFree(s.second.top); (void)hipFree(s.second.topz0); }
     if (g->topq) (void)hipFree(g->topq);
     if (g->eflag) (void)hipFree(g->eflag);
     if (!g->halo_external) for (auto h : g->halo) if (h) (void)hipFree(h);
@@ -792,6 +819,7 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     if (!(t > 0)) return CG_OK;                                           // cg1:437, 600
     const double S = std::max(0.0, std::min(1.0, conformality));          // cg1:440, 603
     const double latRange = t * S;
+    { int rcs = ensure_split(g); if (rcs) return rcs; }
     stats_begin(g);
     if (latRange < std::min(g->dx, g->dy)) {                              // cg1:445, 609
         if (kind == CG_STENCIL_DEPOSIT) return run_depo_vertical(g, mask, mat, t);
@@ -922,7 +950,8 @@ int cg_cmp(cg_grid* g, double depth, int stop_mat) {
     if (stop_mat < 0 || stop_mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", stop_mat);
     g->pend.active = false;
     unsigned qtop = 0;
-    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    int rc = ensure_whole(g); if (rc) return rc;
+    rc = refresh_len_bound(g, &qtop); if (rc) return rc;
     unsigned st[2] = {0, 0};
     if (stop_mat != 0) {
         ProfScope ps(g, CG_K_OTHER);
@@ -947,6 +976,7 @@ int cg_strip_connected(cg_grid* g, int mat) {
     if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "strip_connected on a slab of a decomposed domain is not built yet");
     if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
     g->pend.active = false;
+    { int rcw = ensure_whole(g); if (rcw) return rcw; }
     ProfScope ps(g, CG_K_OTHER);
     const dim3 grid(blocks_for(g->N)), blk(256);
     hipLaunchKernelGGL(k_strip_seed, grid, blk, 0, g->stream, view(g), mat);
@@ -979,7 +1009,8 @@ int cg_identify_cavity(cg_grid* g) {
     if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "identify_cavity with gaps on a slab of a decomposed domain is not built yet");
     g->pend.active = false;
     unsigned qtop = 0;
-    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    int rc = ensure_whole(g); if (rc) return rc;
+    rc = refresh_len_bound(g, &qtop); if (rc) return rc;
     if (g->len_bound >= g->lmax) { rc = grow_planes(g); if (rc) return rc; }       // room for the piece above every column
     const unsigned hmax_q = qtop > 0 ? qtop : (unsigned)js_round(1.0 / g->zscale) & 0xffffu;        // maxHeight() is 1 for a flat-zero grid (cg2:103)
     {
@@ -999,7 +1030,8 @@ int cg_etch_wet_step(cg_grid* g, int mat, int dt_q, int use_diagonal) {
     if (dt_q < 1) return fail(g, CG_ERR_ARG, "etch_wet increment of %d height steps", dt_q);
     g->pend.active = false;
     unsigned qtop = 0;
-    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    int rc = ensure_whole(g); if (rc) return rc;
+    rc = refresh_len_bound(g, &qtop); if (rc) return rc;
     const unsigned Hq = std::max(qtop, 1u);                                                      // cg3:8
     const int dt_diag = std::max(1, (int)std::floor(dt_q * 0.7071067811865476));                 // cg3:92
     {
@@ -1042,7 +1074,8 @@ int cg_ald_collect_seeds(cg_grid* g, double total_thickness, uint64_t* count) {
     if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD on a slab of a decomposed domain is not built yet");
     if (!(total_thickness > 0)) return fail(g, CG_ERR_ARG, "deposit_ALD thickness %g", total_thickness);
     unsigned qtop = 0;
-    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    int rc = ensure_whole(g); if (rc) return rc;
+    rc = refresh_len_bound(g, &qtop); if (rc) return rc;
     const double H0 = qtop > 0 ? (double)qtop * g->zscale : 1.0;
     const AldLayout L = make_bit_layout(g, H0 + total_thickness + g->zscale);                    // cg2:408
     size_t lds = 0;
@@ -1216,6 +1249,7 @@ int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8
     g->pend.active = false;
     HIPCHK(g, hipStreamSynchronize(g->stream));
     if (lmax != g->lmax) { int rc = alloc_planes(g, lmax); if (rc) return rc; }
+    g->split = false;                                       // the scatter kernel writes whole stacks
     const int L = lmax;
     const size_t chunk = std::min<size_t>(g->N, (size_t)1 << 20);
     uint8_t *dm = nullptr, *dl = nullptr; uint16_t* dz = nullptr;
@@ -1252,8 +1286,12 @@ int cg_snapshot_save(cg_grid* g, int slot) {
     cg_snapshot_drop(g, slot);
     Snapshot s; size_t S = g->N * (size_t)g->lmax;
     HIPCHK(g, hipMalloc(&s.len, std::max<size_t>(g->N, 4))); HIPCHK(g, hipMalloc(&s.rec, std::max<size_t>(4 * S, 4)));
+    HIPCHK(g, hipMalloc(&s.top, std::max<size_t>(4 * g->N, 16))); HIPCHK(g, hipMalloc(&s.topz0, std::max<size_t>(2 * g->N, 16)));
     HIPCHK(g, hipMemcpyAsync(s.len, g->len, g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(s.rec, g->rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(s.top, g->top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(s.topz0, g->topz0, 2 * g->N, hipMemcpyDeviceToDevice, g->stream));
+    s.split = g->split;
     s.lmax = g->lmax; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps; s.has_cavity = g->has_cavity;
     g->snaps[slot] = s;
     return CG_OK;
@@ -1269,6 +1307,9 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     size_t S = g->N * (size_t)g->lmax;
     HIPCHK(g, hipMemcpyAsync(g->len, s.len, g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->rec, s.rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(g->top, s.top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(g->topz0, s.topz0, 2 * g->N, hipMemcpyDeviceToDevice, g->stream));
+    g->split = s.split;
     g->len_bound = s.len_bound; g->has_gaps = s.has_gaps; g->has_cavity = s.has_cavity;
     return CG_OK;
 }
@@ -1278,7 +1319,7 @@ int cg_snapshot_drop(cg_grid* g, int slot) {
     auto it = g->snaps.find(slot);
     if (it == g->snaps.end()) return CG_OK;
     HIPCHK(g, hipStreamSynchronize(g->stream));
-    (void)hipFree(it->second.len); (void)hipFree(it->second.rec);
+    (void)hipFree(it->second.len); (void)hipFree(it->second.rec); (void)hipFree(it->second.top); (void)hipFree(it->second.topz0);
     g->snaps.erase(it);
     return CG_OK;
 }
