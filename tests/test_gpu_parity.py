@@ -278,6 +278,62 @@ def test_wet_etch_and_ald_whole_run_entry_points():
     g.close()
 
 
+def test_same_material_runs_across_gaps_and_form_changes():
+    """Isotropic etch whose floor lies under a gap (two layers of one material separated by a stripped
+    layer), appends and removals right after the kernels that restructure columns, and snapshots taken
+    in either internal form of the columns -- against the oracle after every step."""
+    fem = _engine()
+    nx, ny = 120, 88
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    rng = _lcg(5)
+    masks = []
+    for _ in range(2):
+        red = fem.reduce_mask(_random_mask_data(rng, 2 * nx, 8))
+        masks.append((g.mask_from_shapes(red), o.mask_raster(red)))
+    snap = {}
+
+    def both(fn):
+        fn(g, 0); fn(o, 1)
+
+    def step(kind, mi=None, mat=0, t=0.0, S=0.0):
+        gm, om = (None, None) if mi is None else masks[mi]
+        for grid, m in ((g, gm), (o, om)):
+            if kind == "d":
+                grid.deposit_general(m, mat, t, S)
+            elif kind == "e":
+                grid.etch_general(m, mat, t, S)
+            elif kind == "s":
+                grid.strip_connected(mat)
+            elif kind == "p":
+                grid.cmp(t, mat)
+            elif kind == "c":
+                grid.identify_cavity()
+        assert g.checksum() == o.checksum(), (kind, mi, mat, t, S)
+
+    for args in (("d", None, 3, 20), ("d", None, 4, 5), ("d", None, 3, 6), ("d", None, 4, 3), ("d", None, 3, 4),
+                 ("e", 0, 255, 16), ("s", None, 4)):
+        step(*args)
+    g.snapshot_save(1); snap[1] = o.arrays() + (o.Lmax,)           # columns are whole stacks here
+    for args in (("e", None, 3, 9, 1.0), ("e", 1, 3, 2.5, 0.6), ("d", None, 3, 2, 0), ("d", None, 5, 3, 1.0),
+                 ("e", None, 5, 3, 0), ("e", None, 3, 30, 1.0)):
+        step(*args)
+    g.snapshot_save(2); snap[2] = o.arrays() + (o.Lmax,)           # split form here
+    for args in (("p", None, 0, 3), ("d", 1, 3, 7, 0.8), ("s", None, 3), ("d", None, 6, 4, 0), ("e", 0, 6, 4, 0), ("c",)):
+        step(*args)
+    for slot in (1, 2):
+        g.snapshot_load(slot); ln, mat, zp, lm = snap[slot]; o.upload(ln, mat, zp, lm)
+        assert g.checksum() == o.checksum()
+        for args in (("e", None, 3, 5, 1.0), ("d", None, 3, 2.2, 0), ("e", 1, 255, 11, 0), ("d", None, 7, 6, 1.0)):
+            step(*args)
+    ln, mat, zp = g.download(); oln, omat, ozp = o.arrays()
+    L0 = min(g.Lmax, o.Lmax)
+    np.testing.assert_array_equal(ln, oln)
+    np.testing.assert_array_equal(mat.reshape(-1, g.Lmax)[:, :L0], omat.reshape(-1, o.Lmax)[:, :L0])
+    np.testing.assert_array_equal(zp.reshape(-1, g.Lmax, 2)[:, :L0], ozp.reshape(-1, o.Lmax, 2)[:, :L0])
+    g.close()
+
+
 def test_upload_download_roundtrip_and_slices():
     fem = _engine()
     case = load_case("stencil_small")

@@ -26,6 +26,12 @@ for rep in range(2):
         rows.append((k, s, ms, st))
     if rep == 0:
         stats = [r[3] for r in rows]
+    elif os.environ.get("COMPACT"):
+        v = [r[2] for r in rows]
+        print("total %.2f ms | vdep %.2f vetch %.2f sdep %.2f setch %.2f | " % (
+            sum(v), sum(x for x, r in zip(v, rows) if r[1]["kind"] != "ETCH" and r[1]["S"] == 0), sum(x for x, r in zip(v, rows) if r[1]["kind"] == "ETCH" and r[1]["S"] == 0),
+            sum(x for x, r in zip(v, rows) if r[1]["kind"] != "ETCH" and r[1]["S"] > 0), sum(x for x, r in zip(v, rows) if r[1]["kind"] == "ETCH" and r[1]["S"] > 0))
+            + " ".join("%.2f" % x for x in v))
     else:
         for (k, s, ms, _), st in zip(rows, stats):
             by = flows.algorithmic_bytes(s["kind"], st)
