@@ -30,6 +30,7 @@ struct GridView {
     uint8_t*  len;
     uint32_t* rec;
     uint32_t* top;      // split form: the top interval of every column (0 for an empty column)
+    uint32_t* top_w;    // where updated tops are stored: top itself, or the other buffer in a lateral step
     uint16_t* topz0;    // split form: its bottom height
     int       split;    // 1: top interval in top/topz0, planes hold intervals 0..len-2; 0: planes hold all
     size_t    N;        // columns of this handle
@@ -43,7 +44,8 @@ struct GridView {
 constexpr uint32_t REC_HOLE = 1u << 24;     // a vertical gap, not a layer
 constexpr uint32_t REC_MARK = 2u << 24;     // scratch bit of the flood fill (strip_connected)
 constexpr uint32_t REC_RUN  = 4u << 24;     // the nearest layer below has the same material
-__device__ __forceinline__ uint32_t rec_make(uint32_t z1q, int mat) { return (z1q & 0xffffu) | ((uint32_t)(mat & 255) << 16); }
+constexpr uint32_t REC_LAYER = 8u << 24;    // set in every layer record: a record is 0 only where there is none
+__device__ __forceinline__ uint32_t rec_make(uint32_t z1q, int mat) { return (z1q & 0xffffu) | ((uint32_t)(mat & 255) << 16) | REC_LAYER; }
 __device__ __forceinline__ uint32_t rec_z1(uint32_t r) { return r & 0xffffu; }
 __device__ __forceinline__ int rec_mat(uint32_t r) { return (int)((r >> 16) & 255u); }
 __device__ __forceinline__ bool rec_hole(uint32_t r) { return (r & REC_HOLE) != 0; }
@@ -115,10 +117,10 @@ __device__ __forceinline__ int depo_at_top(const GridView& g, size_t c, int l, i
     const uint32_t r = l > 0 ? g.top[c] : 0;
     const uint32_t topq = rec_z1(r);
     const uint16_t q = quantz((double)topq * g.zs + dz, g.zs, g.inv_zs);
-    if (l > 0 && rec_mat(r) == matId) { g.top[c] = rec_with_z1(r, q); return 1; }
+    if (l > 0 && rec_mat(r) == matId) { g.top_w[c] = rec_with_z1(r, q); return 1; }
     if (l >= g.lmax) return 3;
     if (l > 0) g.rec[(size_t)(l - 1) * g.N + c] = r;           // the old top takes its place in the stack
-    g.top[c] = rec_make(q, matId);                             // another material below: RUN stays clear
+    g.top_w[c] = rec_make(q, matId);                           // another material below: RUN stays clear
     g.topz0[c] = (uint16_t)topq;
     g.len[c] = (uint8_t)(l + 1);
     return 2;
@@ -150,7 +152,7 @@ __device__ __forceinline__ int apply_etch_at(const GridView& g, size_t c, int l,
         if (l > 0) reload_top(g, c, l, r, z0q); else { r = 0; z0q = 0; }
     }
     if (touched) {
-        g.top[c] = r;
+        g.top_w[c] = r;
         if (l != l0) { g.topz0[c] = (uint16_t)z0q; g.len[c] = (uint8_t)l; }
     }
     return (touched ? 0x10000 : 0) | removed;
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void k_vertical_1(GridView g, const uint8_t* _
         } else {
             if (only_len >= 0) {
                 if (l != only_len) continue;
-                if (l > 0 && rec_mat(g.top[c]) == matId) continue;
+                if (l > 0 && rec_mat(g.top_w[c]) == matId) continue;     // done in the first pass
             }
             const int r = depo_at_top(g, c, l, matId, t);
             if (r == 3) flags[0] = 1;
@@ -288,7 +290,7 @@ __device__ __forceinline__ void depo_group4(const GridView& g, size_t c0, unsign
         st_u8x4(g.len + c0, nl);
         if (STATS) n_app += __popc(app);
     }
-    st_rec4(g.top + c0, nv);
+    st_rec4(g.top_w + c0, nv);
     if (STATS) n_ext += __popc(ext);
 }
 
@@ -336,7 +338,7 @@ __device__ __forceinline__ void etch_group4(const GridView& g, size_t c0, unsign
     }
     if (dirty) {
         u32x4 nv; nv[0] = r[0]; nv[1] = r[1]; nv[2] = r[2]; nv[3] = r[3];
-        st_rec4(g.top + c0, nv);
+        st_rec4(g.top_w + c0, nv);
         if (popped) {
             u16x4 nz; nz[0] = (unsigned short)z0[0]; nz[1] = (unsigned short)z0[1]; nz[2] = (unsigned short)z0[2]; nz[3] = (unsigned short)z0[3];
             u8x4 nl; nl[0] = (uint8_t)l[0]; nl[1] = (uint8_t)l[1]; nl[2] = (uint8_t)l[2]; nl[3] = (uint8_t)l[3];
@@ -398,93 +400,42 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
 }
 
 // ------------------------------------------------------------------------------------------
-// lateral-stencil steps: snapshot of the tops, halo handling, dilation / erosion + update
+// lateral-stencil steps: dilation / erosion of the top-height map + per-column update
 // ------------------------------------------------------------------------------------------
 //
-// The snapshot is a (nx + 2R) x ny image of u16 top heights (rows R .. R+nx-1 are this
-// handle's rows) and, for etch, a u8 image of "etchable here" flags E (cg1:637-643).
-// The R rows below and above come from the neighbouring slab, or are the clamp-replicated
-// edge row (heights, cg1:373-387) / zero (flags, cg1:671) at a domain edge.
+// A lateral step needs the OLD top height of every column within the kernel radius, and for
+// etch the OLD "etchable here" flag E (cg1:637-643: open in the mask, not empty, top material
+// matches).  Both come straight from the `top` stream; the updated tops go to the other of two
+// buffers (GridView::top_w), which the host swaps in afterwards, so no snapshot pass is needed.
+// Rows beyond the slab come from the neighbouring slab's message, or -- at a domain edge --
+// are the clamp-replicated edge row (heights, cg1:373-387) with zero flags (cg1:671).
+//
+// Message of Rh rows: Rh*ny u16 heights, then Rh*ny u8 flags (zeros for deposit).
+// send_lower = rows 0..Rh-1, send_upper = rows nx-Rh..nx-1.
+__device__ __forceinline__ bool etchable(uint32_t r, int matId, bool isAll) { return r != 0 && (isAll || rec_mat(r) == matId); }
 
-template <bool ETCH>
-__global__ __launch_bounds__(256) void k_snapshot_tops(GridView g, const uint8_t* __restrict__ mask, int matId, int R,
-                                                       uint16_t* __restrict__ topq, uint8_t* __restrict__ eflag) {
+__global__ __launch_bounds__(256) void k_halo_pack(GridView g, const uint8_t* __restrict__ mask, int matId, int etch, int Rh,
+                                                   uint8_t* __restrict__ send_lower, uint8_t* __restrict__ send_upper) {
     const bool isAll = (matId == 255);
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t off = (size_t)R * g.ny;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
-        const int l = g.len[c];
-        const uint32_t r = l > 0 ? g.top[c] : 0;
-        topq[off + c] = (uint16_t)rec_z1(r);
-        if (ETCH) eflag[off + c] = ((!mask || mask[c]) && l > 0 && (isAll || rec_mat(r) == matId)) ? 1 : 0;
-    }
-}
-
-template <bool ETCH>
-__global__ __launch_bounds__(256) void k_snapshot_tops_g4(GridView g, const uint8_t* __restrict__ mask, int matId, int R,
-                                                          uint16_t* __restrict__ topq, uint8_t* __restrict__ eflag) {
-    const bool isAll = (matId == 255);
-    const size_t ngroups = g.N >> 2;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t off = (size_t)R * g.ny;
-    for (size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += stride) {
-        const size_t c0 = gi << 2;
-        const u8x4 ln = ld_u8x4(g.len + c0);
-        const u32x4 tv = ld_rec4(g.top + c0);
-        u16x4 q;
-#pragma unroll
-        for (int j = 0; j < 4; j++) q[j] = ln[j] ? (unsigned short)rec_z1(tv[j]) : (unsigned short)0;
-        *(u16x4*)(topq + off + c0) = q;
-        if (ETCH) {
-            const u8x4 mk = mask ? ld_u8x4(mask + c0) : splat4(1);
-            u8x4 e;
-#pragma unroll
-            for (int j = 0; j < 4; j++) e[j] = (mk[j] && ln[j] > 0 && (isAll || rec_mat(tv[j]) == matId)) ? 1 : 0;
-            st_u8x4(eflag + off + c0, e);
-        }
-    }
-}
-
-// rows to send: first R rows -> lower neighbour, last R rows -> upper neighbour.
-// message layout: R*ny u16 heights, then R*ny u8 flags (zeros for deposit).
-__global__ __launch_bounds__(256) void k_halo_pack(const uint16_t* __restrict__ topq, const uint8_t* __restrict__ eflag, int nx, int ny,
-                                                   int R, uint8_t* __restrict__ send_lower, uint8_t* __restrict__ send_upper) {
-    const size_t n = (size_t)R * ny;
+    const size_t n = (size_t)Rh * g.ny;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-        size_t lo = (size_t)R * ny + e;                     // rows R .. 2R-1 of the image = local rows 0..R-1
-        size_t hi = (size_t)nx * ny + e;                    // rows nx .. nx+R-1 of the image = local rows nx-R..nx-1
-        ((uint16_t*)send_lower)[e] = topq[lo];
-        ((uint16_t*)send_upper)[e] = topq[hi];
-        send_lower[2 * n + e] = eflag ? eflag[lo] : 0;
-        send_upper[2 * n + e] = eflag ? eflag[hi] : 0;
+        const size_t lo = e, hi = (size_t)(g.nx - Rh) * g.ny + e;
+        const uint32_t rl = g.top[lo], rh = g.top[hi];
+        ((uint16_t*)send_lower)[e] = (uint16_t)rec_z1(rl);
+        ((uint16_t*)send_upper)[e] = (uint16_t)rec_z1(rh);
+        send_lower[2 * n + e] = (etch && (!mask || mask[lo]) && etchable(rl, matId, isAll)) ? 1 : 0;
+        send_upper[2 * n + e] = (etch && (!mask || mask[hi]) && etchable(rh, matId, isAll)) ? 1 : 0;
     }
 }
 
-// fill the halo rows of the image from the received messages, or from the edge rule
-__global__ __launch_bounds__(256) void k_halo_unpack(uint16_t* __restrict__ topq, uint8_t* __restrict__ eflag, int nx, int ny, int R,
-                                                     const uint8_t* __restrict__ recv_lower, const uint8_t* __restrict__ recv_upper) {
-    const size_t n = (size_t)R * ny;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
-        int j = (int)(e % ny);
-        size_t lo = e;                                      // rows 0 .. R-1
-        size_t hi = (size_t)(nx + R) * ny + e;              // rows nx+R .. nx+2R-1
-        if (recv_lower) {
-            topq[lo] = ((const uint16_t*)recv_lower)[e];
-            if (eflag) eflag[lo] = recv_lower[2 * n + e];
-        } else {
-            topq[lo] = topq[(size_t)R * ny + j];            // replicate local row 0
-            if (eflag) eflag[lo] = 0;
-        }
-        if (recv_upper) {
-            topq[hi] = ((const uint16_t*)recv_upper)[e];
-            if (eflag) eflag[hi] = recv_upper[2 * n + e];
-        } else {
-            topq[hi] = topq[(size_t)(nx + R - 1) * ny + j]; // replicate local row nx-1
-            if (eflag) eflag[hi] = 0;
-        }
-    }
+// Where the heights of local row `il` (any integer) come from.
+struct RowSrc { const uint8_t* msg; int row; bool edge; };     // msg != 0: message row `row`; else grid row `row`
+__device__ __forceinline__ RowSrc row_source(const GridView& g, int il, int Rh, const uint8_t* halo_lo, const uint8_t* halo_up) {
+    RowSrc s; s.msg = nullptr; s.row = il; s.edge = false;
+    if (il < 0) { if (halo_lo) { s.msg = halo_lo; s.row = Rh + il; } else { s.row = 0; s.edge = true; } }
+    else if (il >= g.nx) { if (halo_up) { s.msg = halo_up; s.row = il - g.nx; } else { s.row = g.nx - 1; s.edge = true; } }
+    return s;
 }
 
 // One stencil tap: LDS offset relative to the centre (du*pitch + dv) and the float32 height
@@ -510,7 +461,7 @@ __host__ __device__ inline size_t stencil_lds_bytes(int R) { return (size_t)(TI 
 // General form: any radius that fits the LDS, tap list at run time, one column at a time.
 template <bool ETCH, bool STATS>
 __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t* __restrict__ mask, int matId, double t, int R,
-                                                       const uint16_t* __restrict__ topq, const uint8_t* __restrict__ eflag,
+                                                       const uint8_t* __restrict__ halo_lo, const uint8_t* __restrict__ halo_up,
                                                        const Tap* __restrict__ taps, int ntaps,
                                                        const Tap* __restrict__ taps64, int ntaps64,
                                                        int only_len, int* __restrict__ flags, unsigned long long* gstats) {
@@ -522,19 +473,29 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
     const int i_base = tile_i * TI, j_base = tile_j * TJ;
 
     // ---- stage heights (as float32 of q*zscale, cg1:465) with halo; flags fold into +inf
+    const bool isAll = (matId == 255);
+    const size_t msg_n = (size_t)R * g.ny;
     for (int e = threadIdx.x; e < tile_rows * pitch; e += 256) {
-        int r = e / pitch, cidx = e - r * pitch;
-        int irow = i_base + r;                         // row in the (nx+2R) image
-        int j = j_base + cidx - R;
-        float h;
-        if (irow >= g.nx + 2 * R) { h = ETCH ? __builtin_inff() : 0.f; }
-        else {
-            bool outside = (j < 0 || j >= g.ny);
-            int jc = j < 0 ? 0 : (j >= g.ny ? g.ny - 1 : j);        // clamp-replicate in j (cg1:374-380)
-            size_t p = (size_t)irow * g.ny + jc;
-            h = (float)((double)topq[p] * g.zs);
-            if (ETCH && (outside || !eflag[p])) h = __builtin_inff();   // not etchable: never a minimum (cg1:718)
+        const int r = e / pitch, cidx = e - r * pitch;
+        const int j = j_base + cidx - R;
+        const bool outside = (j < 0 || j >= g.ny);
+        const int jc = j < 0 ? 0 : (j >= g.ny ? g.ny - 1 : j);            // clamp-replicate in j (cg1:374-380)
+        const RowSrc src = row_source(g, i_base + r - R, R, halo_lo, halo_up);
+        unsigned q = 0; bool ok = false;
+        if (src.msg) {
+            if (src.row >= 0 && src.row < R) {
+                const size_t p = (size_t)src.row * g.ny + jc;
+                q = ((const uint16_t*)src.msg)[p];
+                ok = src.msg[2 * msg_n + p] != 0;
+            }
+        } else {
+            const size_t p = (size_t)src.row * g.ny + jc;
+            const uint32_t rr = g.top[p];
+            q = rec_z1(rr);
+            if (ETCH) ok = !src.edge && (!mask || mask[p]) && etchable(rr, matId, isAll);
         }
+        float h = (float)((double)q * g.zs);
+        if (ETCH && (outside || !ok)) h = __builtin_inff();               // not etchable: never a minimum (cg1:718)
         s_h[e] = h;
     }
     __syncthreads();
@@ -542,7 +503,6 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j = j_base + tx;
     unsigned loc[4] = {0, 0, 0, 0};
-    const bool isAll = (matId == 255);
 
     if (j < g.ny) {
         float m[ROWS_PER_THREAD];
@@ -556,11 +516,12 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
             lbase[r] = (ty + 4 * r + R) * pitch + (tx + R);
             if (il < g.nx) {
                 size_t c = (size_t)il * g.ny + j;
-                size_t p = (size_t)(il + R) * g.ny + j;
-                float h = (float)((double)topq[p] * g.zs);
+                const uint32_t rr = g.top[c];
+                float h = (float)((double)rec_z1(rr) * g.zs);
                 own[r] = h;
+                if (only_len < 0 && g.top_w != g.top) g.top_w[c] = rr;    // columns that stay as they are
                 if (ETCH) {
-                    act[r] = eflag[p] != 0;
+                    act[r] = (!mask || mask[c]) && etchable(rr, matId, isAll);
                     m[r] = (float)((double)h - t);                     // cg1:702
                 } else {
                     act[r] = (!mask || mask[c]);
@@ -612,7 +573,7 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 } else {
                     if (only_len >= 0) {
                         if (l != only_len) continue;
-                        if (l > 0 && rec_mat(g.top[c]) == matId) continue;
+                        if (l > 0 && rec_mat(g.top_w[c]) == matId) continue;     // done in the first pass
                     }
                     double dz = (double)m[r] - (double)own[r];         // cg1:534-536
                     if (STATS) loc[0]++;
@@ -655,7 +616,7 @@ template <int R, int TJS> struct SymGeom {
 // Rimg = halo rows of the snapshot image (the cached kernel's Rx, >= R).
 template <int R, int TJS, bool ETCH, bool STATS>
 __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* __restrict__ mask, int matId, double t, int Rimg,
-                                                     const uint16_t* __restrict__ topq, const uint8_t* __restrict__ eflag,
+                                                     const uint8_t* __restrict__ halo_lo, const uint8_t* __restrict__ halo_up,
                                                      const AddTab<R> tab, const Tap* __restrict__ taps64, int ntaps64,
                                                      int* __restrict__ flags, unsigned long long* gstats) {
     using G = SymGeom<R, TJS>;
@@ -669,28 +630,40 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
     const float INF = __builtin_inff();
 
     // ---- stage float32(q*zscale) (cg1:465) with halo; not-etchable cells become +inf (cg1:718)
+    const bool isAll = (matId == 255);
+    const size_t msg_n = (size_t)Rimg * g.ny;
     for (int e = threadIdx.x; e < ROWS * GPR; e += 256) {
         const int r = e / GPR, gq = e - r * GPR;
-        const int irow = i_base + r + (Rimg - R);
         const int j4 = j_base - Rp + 4 * gq;
-        float4 h;
-        if (irow >= g.nx + 2 * Rimg) { const float v = ETCH ? INF : 0.f; h = make_float4(v, v, v, v); }
-        else {
-            const bool left = j4 < 0, right = j4 >= g.ny;
-            const int jc = left ? 0 : (right ? g.ny - 4 : j4);
-            const size_t p = (size_t)irow * g.ny + jc;
-            u16x4 q = *(const u16x4*)(topq + p);
-            if (left) q = (u16x4)(q[0]);               // clamp-replicate in j (cg1:374-380)
-            if (right) q = (u16x4)(q[3]);
-            h.x = (float)((double)q[0] * g.zs); h.y = (float)((double)q[1] * g.zs);
-            h.z = (float)((double)q[2] * g.zs); h.w = (float)((double)q[3] * g.zs);
-            if (ETCH) {
-                if (left || right) h = make_float4(INF, INF, INF, INF);      // flags are zero outside the domain (cg1:671)
-                else {
-                    const u8x4 e4 = ld_u8x4(eflag + p);
-                    if (!e4[0]) h.x = INF; if (!e4[1]) h.y = INF; if (!e4[2]) h.z = INF; if (!e4[3]) h.w = INF;
-                }
+        const bool left = j4 < 0, right = j4 >= g.ny;
+        const int jc = left ? 0 : (right ? g.ny - 4 : j4);
+        const RowSrc src = row_source(g, i_base + r - R, Rimg, halo_lo, halo_up);
+        u16x4 q = (u16x4)(0); u8x4 e4 = splat4(0);
+        if (src.msg) {
+            if (src.row >= 0 && src.row < Rimg) {
+                const size_t p = (size_t)src.row * g.ny + jc;
+                q = *(const u16x4*)((const uint16_t*)src.msg + p);
+                if (ETCH) e4 = ld_u8x4(src.msg + 2 * msg_n + p);
             }
+        } else {
+            const size_t p = (size_t)src.row * g.ny + jc;
+            const u32x4 tv = ld_rec4(g.top + p);
+            q[0] = (unsigned short)rec_z1(tv[0]); q[1] = (unsigned short)rec_z1(tv[1]);
+            q[2] = (unsigned short)rec_z1(tv[2]); q[3] = (unsigned short)rec_z1(tv[3]);
+            if (ETCH && !src.edge) {
+                const u8x4 mk = mask ? ld_u8x4(mask + p) : splat4(1);
+#pragma unroll
+                for (int c = 0; c < 4; c++) e4[c] = (mk[c] && etchable(tv[c], matId, isAll)) ? 1 : 0;
+            }
+        }
+        if (left) q = (u16x4)(q[0]);                   // clamp-replicate in j (cg1:374-380)
+        if (right) q = (u16x4)(q[3]);
+        float4 h;
+        h.x = (float)((double)q[0] * g.zs); h.y = (float)((double)q[1] * g.zs);
+        h.z = (float)((double)q[2] * g.zs); h.w = (float)((double)q[3] * g.zs);
+        if (ETCH) {
+            if (left || right) h = make_float4(INF, INF, INF, INF);          // flags are zero outside the domain (cg1:671)
+            else { if (!e4[0]) h.x = INF; if (!e4[1]) h.y = INF; if (!e4[2]) h.z = INF; if (!e4[3]) h.w = INF; }
         }
         *(float4*)(s_h + r * PITCH + 4 * gq) = h;
     }
@@ -701,9 +674,13 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
     unsigned loc[4] = {0, 0, 0, 0};
     if (il < g.nx && j0 < g.ny) {
         const size_t c0 = (size_t)il * g.ny + j0;
-        unsigned act;
-        if (ETCH) act = open_bits(ld_u8x4(eflag + (size_t)(il + Rimg) * g.ny + j0));
-        else act = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
+        const u32x4 tv = ld_rec4(g.top + c0);
+        if (g.top_w != g.top) st_rec4(g.top_w + c0, tv);                   // columns that stay as they are
+        unsigned act = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
+        if (ETCH) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) if (!etchable(tv[c], matId, isAll)) act &= ~(1u << c);
+        }
         if (act) {
             const float* rowc = s_h + (ry + R) * PITCH + 4 * gx;
             float hc[W];
@@ -769,7 +746,6 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
 #undef CG_ADD
             // ---- per-column update
             const u8x4 ln = ld_u8x4(g.len + c0);
-            const u32x4 tv = ld_rec4(g.top + c0);
             double dz[4] = {0, 0, 0, 0};
             unsigned open = 0;
             if (STATS) loc[0] += __popc(act);
@@ -782,7 +758,6 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                 }
                 if (open) depo_group4<STATS>(g, c0, open, ln, dz, matId, tv, flags, loc[1], loc[2]);
             } else {
-                const bool isAll = (matId == 255);
                 const u16x4 zv = ld_u16x4(g.topz0 + c0);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {

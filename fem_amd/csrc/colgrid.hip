@@ -77,12 +77,12 @@ struct cg_grid {
     int lmax = 32;
     uint8_t* len = nullptr; uint32_t* rec = nullptr;      // see cg_kernels.hip.h for the layout
     uint32_t* top = nullptr; uint16_t* topz0 = nullptr;   // split form: top interval of every column and its bottom
+    uint32_t* top_alt = nullptr;                          // the buffer a lateral step writes its new tops to (then swapped)
     bool split = true;                                    // which form the columns are in right now
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<uint8_t*> masks;
     std::deque<ConfKernel*> kcache;
-    // stencil scratch
-    uint16_t* topq = nullptr; uint8_t* eflag = nullptr; size_t img_cap = 0;     // capacity in elements
+    // halo messages of a lateral step on a slab
     uint8_t* halo[4] = {nullptr, nullptr, nullptr, nullptr}; size_t halo_cap = 0;  // send lo/up, recv lo/up
     Pending pend;
     std::map<int, Snapshot> snaps;
@@ -167,7 +167,7 @@ int js_to_int32(double v) {                  // (v | 0)
 
 GridView view(const cg_grid* g) {
     GridView v;
-    v.len = g->len; v.rec = g->rec; v.top = g->top; v.topz0 = g->topz0; v.split = g->split ? 1 : 0;
+    v.len = g->len; v.rec = g->rec; v.top = g->top; v.top_w = g->top; v.topz0 = g->topz0; v.split = g->split ? 1 : 0;
     v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
     return v;
 }
@@ -182,7 +182,8 @@ void free_planes(cg_grid* g) {
     if (g->rec) (void)hipFree(g->rec);
     if (g->top) (void)hipFree(g->top);
     if (g->topz0) (void)hipFree(g->topz0);
-    g->len = nullptr; g->rec = nullptr; g->top = nullptr; g->topz0 = nullptr;
+    if (g->top_alt) (void)hipFree(g->top_alt);
+    g->len = nullptr; g->rec = nullptr; g->top = nullptr; g->topz0 = nullptr; g->top_alt = nullptr;
 }
 
 int alloc_planes(cg_grid* g, int lmax) {
@@ -192,6 +193,7 @@ int alloc_planes(cg_grid* g, int lmax) {
     HIPCHK(g, hipMalloc(&g->rec, std::max<size_t>(4 * S, 4)));
     HIPCHK(g, hipMalloc(&g->top, std::max<size_t>(4 * g->N, 16)));
     HIPCHK(g, hipMalloc(&g->topz0, std::max<size_t>(2 * g->N, 16)));
+    HIPCHK(g, hipMalloc(&g->top_alt, std::max<size_t>(4 * g->N, 16)));
     g->lmax = lmax;
     return CG_OK;
 }
@@ -370,17 +372,8 @@ int upload_taps(cg_grid* g, ConfKernel* k, int R) {
     return CG_OK;
 }
 
-int ensure_stencil_scratch(cg_grid* g, int R, bool etch) {
-    size_t need = (size_t)(g->nx + 2 * R) * g->ny;
-    if (need > g->img_cap) {
-        if (g->topq) (void)hipFree(g->topq);
-        if (g->eflag) (void)hipFree(g->eflag);
-        g->topq = nullptr; g->eflag = nullptr; g->img_cap = 0;
-        HIPCHK(g, hipMalloc(&g->topq, need * sizeof(uint16_t)));
-        HIPCHK(g, hipMalloc(&g->eflag, need));
-        g->img_cap = need;
-    }
-    (void)etch;
+int ensure_stencil_scratch(cg_grid* g, int R, bool need_halo) {
+    if (!need_halo) return CG_OK;
     size_t hneed = (size_t)R * g->ny * 3;
     if (hneed > g->halo_cap && g->halo_external)
         return fail(g, CG_ERR_ARG, "caller's halo buffers hold %zu bytes each, this step needs %zu", g->halo_cap, hneed);
@@ -421,7 +414,11 @@ int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
     return CG_OK;
 }
 
-int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t_eff, int R, ConfKernel* K, int only_len) {
+// New tops go to top_alt (the caller swaps the buffers when the step is complete).
+int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t_eff, int R, ConfKernel* K, int only_len,
+                   const uint8_t* halo_lo, const uint8_t* halo_up) {
+    GridView gv = view(g);
+    gv.top_w = g->top_alt;
     const int tiles = ((g->nx + TI - 1) / TI) * ((g->ny + TJ - 1) / TJ);
     const size_t lds = stencil_lds_bytes(R);
     const dim3 grid(tiles), blk(256);
@@ -433,7 +430,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
         AddTab<RR> tab; memcpy(tab.a, K->quad.data(), sizeof tab.a);                                           \
         const int tis = 1024 / TT;                                                                             \
         const dim3 gridS(((g->nx + tis - 1) / tis) * ((g->ny + TT - 1) / TT));                                 \
-        hipLaunchKernelGGL((k_stencil_sym<RR, TT, E, S>), gridS, blk, 0, g->stream, view(g), mask, mat, t_eff, R, g->topq, g->eflag, \
+        hipLaunchKernelGGL((k_stencil_sym<RR, TT, E, S>), gridS, blk, 0, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
                            tab, K->d_taps64_sym, K->ntaps64_sym, g->d_flags, g->d_stats);                      \
     } while (0)
 #define SYM_T(RR, E, S) do { if (tjs == 64) SYM(RR, 64, E, S); else if (tjs == 128) SYM(RR, 128, E, S); else SYM(RR, 256, E, S); } while (0)
@@ -456,7 +453,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
     do {                                                                                                       \
         if (lds > 48 * 1024)                                                                                   \
             HIPCHK(g, hipFuncSetAttribute((const void*)k_stencil_apply<E, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_stencil_apply<E, S>), grid, blk, lds, g->stream, view(g), mask, mat, t_eff, R, g->topq, g->eflag, \
+        hipLaunchKernelGGL((k_stencil_apply<E, S>), grid, blk, lds, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
                            K->d_taps, K->ntaps, K->d_taps64, K->ntaps64, only_len, g->d_flags, g->d_stats);    \
     } while (0)
     if (etch) { if (g->stats_on) LAUNCH(true, true); else LAUNCH(true, false); }
@@ -680,8 +677,6 @@ int cg_destroy(cg_grid* g) {
     for (auto m : g->masks) if (m) (void)hipFree(m);
     for (auto k : g->kcache) free_kernel(k);
     for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.rec); (void)hipFree(s.second.top); (void)hipFree(s.second.topz0); }
-    if (g->topq) (void)hipFree(g->topq);
-    if (g->eflag) (void)hipFree(g->eflag);
     if (!g->halo_external) for (auto h : g->halo) if (h) (void)hipFree(h);
     for (auto& r : g->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
@@ -840,26 +835,12 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     if (stencil_lds_bytes(R) > 160 * 1024) return fail(g, CG_ERR_UNSUPPORTED, "stencil radius %d cells does not fit the LDS tile", R);
     if ((has_lower || has_upper) && g->nx < R)
         return fail(g, CG_ERR_UNSUPPORTED, "slab of %d rows is thinner than the stencil radius %d", g->nx, R);
-    int rc = ensure_stencil_scratch(g, R, kind == CG_STENCIL_ETCH); if (rc) return rc;
+    int rc = ensure_stencil_scratch(g, R, has_lower || has_upper); if (rc) return rc;
     rc = upload_taps(g, K, R); if (rc) return rc;
-    const dim3 grid(blocks_for(g->N)), blk(256);
-    {
-        ProfScope ps(g, CG_K_SNAPSHOT);
-        if (g->N % 4 == 0) {
-            const dim3 grid4(blocks_for(g->N / 4));
-            if (kind == CG_STENCIL_ETCH) hipLaunchKernelGGL(k_snapshot_tops_g4<true>, grid4, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag);
-            else hipLaunchKernelGGL(k_snapshot_tops_g4<false>, grid4, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag);
-        } else if (kind == CG_STENCIL_ETCH) {
-            hipLaunchKernelGGL(k_snapshot_tops<true>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag);
-        } else {
-            hipLaunchKernelGGL(k_snapshot_tops<false>, grid, blk, 0, g->stream, view(g), mask, mat, R, g->topq, g->eflag);
-        }
-    }
-    HIPCHK(g, hipGetLastError());
     if (has_lower || has_upper) {
         ProfScope ps(g, CG_K_HALO);
-        hipLaunchKernelGGL(k_halo_pack, dim3(blocks_for((size_t)R * g->ny)), blk, 0, g->stream, g->topq,
-                           kind == CG_STENCIL_ETCH ? g->eflag : (const uint8_t*)nullptr, g->nx, g->ny, R, g->halo[0], g->halo[1]);
+        hipLaunchKernelGGL(k_halo_pack, dim3(blocks_for((size_t)R * g->ny)), dim3(256), 0, g->stream, view(g), mask, mat,
+                           kind == CG_STENCIL_ETCH ? 1 : 0, R, g->halo[0], g->halo[1]);
         HIPCHK(g, hipGetLastError());
     }
     g->pend.active = true; g->pend.kind = kind; g->pend.mask_id = mask_id; g->pend.mat = mat; g->pend.R = R; g->pend.K = K;
@@ -904,25 +885,27 @@ int cg_stencil_finish(cg_grid* g) {
     bool ok; const uint8_t* mask = mask_ptr(g, p.mask_id, &ok);
     if (!ok) return fail(g, CG_ERR_ARG, "mask %d vanished during the step", p.mask_id);
     const bool etch = p.kind == CG_STENCIL_ETCH;
-    { ProfScope ps(g, CG_K_HALO);
-    hipLaunchKernelGGL(k_halo_unpack, dim3(blocks_for((size_t)p.R * g->ny)), dim3(256), 0, g->stream, g->topq,
-                       etch ? g->eflag : (uint8_t*)nullptr, g->nx, g->ny, p.R, p.has_lower ? g->halo[2] : (const uint8_t*)nullptr,
-                       p.has_upper ? g->halo[3] : (const uint8_t*)nullptr); }
-    HIPCHK(g, hipGetLastError());
-    if (etch) return launch_stencil(g, true, mask, p.mat, p.t_eff, p.R, p.K, -1);
+    const uint8_t* halo_lo = p.has_lower ? g->halo[2] : nullptr;
+    const uint8_t* halo_up = p.has_upper ? g->halo[3] : nullptr;
+    if (etch) {
+        int rc = launch_stencil(g, true, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up); if (rc) return rc;
+        std::swap(g->top, g->top_alt);
+        return CG_OK;
+    }
 
     bool may_overflow = g->len_bound >= g->lmax;
     if (may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; may_overflow = g->len_bound >= g->lmax; }
     if (may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
-    int rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1); if (rc) return rc;
+    int rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up); if (rc) return rc;
     if (may_overflow) {
         int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
         if (fl[0]) {
             const int oldL = g->lmax;
             rc = grow_planes(g); if (rc) return rc;
-            rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, oldL); if (rc) return rc;
+            rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, oldL, halo_lo, halo_up); if (rc) return rc;
         }
     }
+    std::swap(g->top, g->top_alt);
     if (g->len_bound < 255) g->len_bound += 1;
     // identify_cavity (cg1:543) -- a no-op while no column has a vertical gap
     if (g->has_gaps || g->has_cavity) return cg_identify_cavity(g);
