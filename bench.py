@@ -174,10 +174,19 @@ def main():
         cand = {n_: v for n_, v in kernels.items() if "GBps" in v}
         dom = max(cand, key=lambda n_: cand[n_]["ms_total"]) if cand else None
         roofline = None
+        # HBM traffic per launch from the PMC passes of the same command (tools/prof.sh), when committed
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+        if dom and os.path.exists(tpath) and args.n == 16384 and args.flow == "c4":
+            with open(tpath) as f:
+                tj = json.load(f)
+            if dom in tj.get("kernels", {}):
+                traffic = tj["kernels"][dom]["fetch_bytes_per_launch"] + tj["kernels"][dom]["write_bytes_per_launch"]
+                traffic_src = "profiles/r01_traffic.json"
         if dom:
             achieved = cand[dom]["GBps"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(achieved / 8000.0, 4), "traffic": None,
+                        "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "launches": cand[dom]["launches"], "ms_avg": cand[dom]["ms_avg"],
                         "algorithmic_bytes_per_launch": int(kbytes[dom] / max(1, cand[dom]["launches"]))}
         total_alg = sum(step_bytes[(k + q) % len(flow)] for q in range(args.steps))

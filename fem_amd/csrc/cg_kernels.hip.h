@@ -360,14 +360,16 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
     const size_t tile_groups = (size_t)256 * U;
     const size_t ntiles = (ngroups + tile_groups - 1) / tile_groups;
     const double dz[4] = {t, t, t, t};
-    // Workgroup b always runs on the same XCD (b mod 8 in practice) and a fixed stride would hand it
-    // the same column range of every row; a masked step whose open area covers some column ranges
-    // only would then load the XCDs unevenly.  Rotating the assignment by one tile per sweep
-    // spreads every column range over all XCDs.
+    // Workgroup b runs on XCD b mod 8, and tile b of every image row covers the same column range;
+    // a masked step whose open area covers some column ranges only would then load the XCDs
+    // unevenly.  Rotating the tiles of image row r by r (and the sweeps of a capped grid by the
+    // sweep number) spreads every column range over all XCDs.
+    const size_t row_tiles = ((size_t)(g.ny >> 2) % tile_groups == 0) ? (size_t)(g.ny >> 2) / tile_groups : 0;
     const size_t nsweeps = (ntiles + gridDim.x - 1) / gridDim.x;
     for (size_t sweep = 0; sweep < nsweeps; sweep++) {
-        const size_t tile = sweep * gridDim.x + (blockIdx.x + sweep) % gridDim.x;
+        size_t tile = sweep * gridDim.x + (blockIdx.x + sweep) % gridDim.x;
         if (tile >= ntiles) continue;
+        if (row_tiles > 1) { const size_t r = tile / row_tiles, q = tile - r * row_tiles; tile = r * row_tiles + (q + r) % row_tiles; }
         const size_t gbase = tile * tile_groups + threadIdx.x;
         u8x4 ln[U]; unsigned open[U]; u32x4 tv[U]; u16x4 zv[U];
 #pragma unroll

@@ -39,3 +39,43 @@ for k in sorted(agg):
     print("  " + k)
     for c in sorted(agg[k]):
         print("      %-22s %18.1f   (n=%d)" % (c, agg[k][c] / cnt[k][c], cnt[k][c]))
+
+# HBM traffic per launch by the labels bench.py uses (FETCH_SIZE / WRITE_SIZE count kilobytes)
+import json
+import re
+
+
+def label(k):
+    m = re.match(r"k_(stencil_sym|stencil_apply|vertical_g4|vertical_1)<(.*)>", k)
+    if not m:
+        return None
+    args = [a.strip() for a in m.group(2).split(",")]
+    if m.group(1) == "stencil_sym":
+        etch = args[2]
+        return "k_stencil_sym<%s>" % ("etch" if etch == "true" else "deposit")
+    if m.group(1) == "stencil_apply":
+        return "k_stencil_sym<%s>" % ("etch" if args[0] == "true" else "deposit")
+    return "k_vertical_g4<%s>" % ("etch" if args[0] == "true" else "deposit")
+
+
+tr = defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0, "nf": 0, "nw": 0})
+for k in agg:
+    lb = label(k)
+    if not lb:
+        continue
+    if "FETCH_SIZE" in agg[k]:
+        tr[lb]["fetch_kb"] += agg[k]["FETCH_SIZE"]; tr[lb]["nf"] += cnt[k]["FETCH_SIZE"]
+    if "WRITE_SIZE" in agg[k]:
+        tr[lb]["write_kb"] += agg[k]["WRITE_SIZE"]; tr[lb]["nw"] += cnt[k]["WRITE_SIZE"]
+res = {}
+for lb, v in tr.items():
+    if v["nf"] and v["nw"]:
+        res[lb] = {"fetch_bytes_per_launch": round(2 * v["fetch_kb"] * 1024 / v["nf"]), "write_bytes_per_launch": round(v["write_kb"] * 1024 / v["nw"]),
+                   "launches_profiled": min(v["nf"], v["nw"])}
+if res:
+    with open(os.path.join(out, "traffic.json"), "w") as f:
+        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python3 bench.py --no-cpu; counters are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B; checked on the substrate step, which reads len only: 268 MB expected, 131 MiB-units reported)",
+                   "kernels": res}, f, indent=1)
+    print("== HBM traffic per launch (bytes)")
+    for lb, v in sorted(res.items()):
+        print("  %-28s fetch %14d  write %14d  (n=%d)" % (lb, v["fetch_bytes_per_launch"], v["write_bytes_per_launch"], v["launches_profiled"]))
