@@ -254,8 +254,9 @@ __device__ __forceinline__ void st_u16x4(uint16_t* p, u16x4 v) { *(u16x4*)p = v;
 __device__ __forceinline__ unsigned open_bits(u8x4 mk) { return (mk[0] ? 1u : 0u) | (mk[1] ? 2u : 0u) | (mk[2] ? 4u : 0u) | (mk[3] ? 8u : 0u); }
 
 // _depoAtTop_ on the open columns of a group: column j grows by dz[j] (> 0).  tv = the 4 tops.
+// Returns whether the group's tops were stored.
 template <bool STATS>
-__device__ __forceinline__ void depo_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
+__device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
                                             u32x4 tv, int* __restrict__ flags, unsigned& n_ext, unsigned& n_app) {
     u32x4 nv = tv; u8x4 nl = ln;
     unsigned ext = 0, app = 0;
@@ -269,7 +270,7 @@ __device__ __forceinline__ void depo_group4(const GridView& g, size_t c0, unsign
         else if (l >= g.lmax) flags[0] = 1;      // no plane left: the host grows the planes and re-runs these columns
         else { nv[j] = rec_make(q, matId); nl[j] = (uint8_t)(l + 1); app |= 1u << j; }
     }
-    if (!(ext | app)) return;
+    if (!(ext | app)) return false;
     if (app) {
         // the old tops move into the stack
         const int l0 = ln[0];
@@ -292,13 +293,14 @@ __device__ __forceinline__ void depo_group4(const GridView& g, size_t c0, unsign
     }
     st_rec4(g.top_w + c0, nv);
     if (STATS) n_ext += __popc(ext);
+    return true;
 }
 
 // _applyEtchAt on the open columns of a group: column j loses dz[j] (> 0) from the top.
 // tv / zv = the 4 tops and their bottoms.  A column that loses its whole top layer reloads the
 // next one from the planes; columns doing so at the same length share the vector loads.
 template <bool STATS>
-__device__ __forceinline__ void etch_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
+__device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
                                             bool isAll, u32x4 tv, u16x4 zv, unsigned& n_touched, unsigned& n_removed) {
     int l[4] = {ln[0], ln[1], ln[2], ln[3]};
     uint32_t r[4] = {tv[0], tv[1], tv[2], tv[3]};
@@ -347,6 +349,7 @@ __device__ __forceinline__ void etch_group4(const GridView& g, size_t c0, unsign
         }
     }
     if (STATS) n_touched += __popc(dirty);
+    return dirty != 0;
 }
 
 // Vertical deposit / etch (fast paths, cg1:445-454 and 609-618).  A thread owns U groups that
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
     if (il < g.nx && j0 < g.ny) {
         const size_t c0 = (size_t)il * g.ny + j0;
         const u32x4 tv = ld_rec4(g.top + c0);
-        if (g.top_w != g.top) st_rec4(g.top_w + c0, tv);                   // columns that stay as they are
+        bool stored = false;
         unsigned act = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
         if (ETCH) {
 #pragma unroll
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                     const double d = (double)m[c] - (double)own[c];          // cg1:534-537
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) depo_group4<STATS>(g, c0, open, ln, dz, matId, tv, flags, loc[1], loc[2]);
+                if (open) stored = depo_group4<STATS>(g, c0, open, ln, dz, matId, tv, flags, loc[1], loc[2]);
             } else {
                 const u16x4 zv = ld_u16x4(g.topz0 + c0);
 #pragma unroll
@@ -771,9 +774,10 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                     const double d = (double)own[c] - (double)hpv;
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) etch_group4<STATS>(g, c0, open, ln, dz, matId, isAll, tv, zv, loc[1], loc[2]);
+                if (open) stored = etch_group4<STATS>(g, c0, open, ln, dz, matId, isAll, tv, zv, loc[1], loc[2]);
             }
         }
+        if (!stored && g.top_w != g.top) st_rec4(g.top_w + c0, tv);       // columns that stay as they are
     }
     if (STATS) {
         if (ETCH) { const int slot[4] = {ST_OPEN, ST_ETCHED, ST_REMOVED, ST_FLOOR}; stats_commit<4>(gstats, loc, slot); }

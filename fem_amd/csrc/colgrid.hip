@@ -28,7 +28,7 @@ template <bool ETCH>
 static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t);
 // columns per tile row of the symmetric stencil kernel (tuning knob: env CG_TJS = 64, 128, 256)
 static int sym_tile_cols() {
-    static int v = [] { const char* e = getenv("CG_TJS"); int x = e ? atoi(e) : 256; return (x == 64 || x == 128 || x == 256) ? x : 256; }();
+    static int v = [] { const char* e = getenv("CG_TJS"); int x = e ? atoi(e) : 64; return (x == 64 || x == 128 || x == 256) ? x : 64; }();
     return v;
 }
 
