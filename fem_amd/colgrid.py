@@ -71,6 +71,15 @@ ABI = {
     "cg_cmp": (_i, [_vp, _d, _i]),
     "cg_strip_connected": (_i, [_vp, _i]),
     "cg_identify_cavity": (_i, [_vp]),
+    "cg_cmp_scan": (_i, [_vp, _i, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(_i)]),
+    "cg_cmp_apply": (_i, [_vp, _d, _i]),
+    "cg_cavity_state": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(C.c_uint32)]),
+    "cg_cavity_fill": (_i, [_vp, C.c_uint32]),
+    "cg_ghost_bytes": (_i, [_vp, _i, C.POINTER(_sz)]),
+    "cg_ghost_pack": (_i, [_vp, _i, _vp, _vp]),
+    "cg_strip_seed": (_i, [_vp, _i, _i, _vp, _vp]),
+    "cg_strip_sweep": (_i, [_vp, _i, _i, _vp, _vp, C.POINTER(_i)]),
+    "cg_strip_finish": (_i, [_vp]),
     "cg_etch_wet": (_i, [_vp, _i, _d, _d]),
     "cg_etch_wet_step": (_i, [_vp, _i, _i, _i]),
     "cg_deposit_ald": (_i, [_vp, _i, _d, _d]),
@@ -331,6 +340,48 @@ class ColumnGrid:
 
     def identify_cavity(self):
         self._chk(self.lib.cg_identify_cavity(self.h))
+
+    # ---- cmp / strip_connected / identify_cavity in the pieces a slab driver needs (see include/colgrid.h)
+    def cmp_scan(self, stopMatId):
+        """-> (top_q, stopper_q, stopper_found) of this handle's columns."""
+        a, b, f = C.c_uint32(), C.c_uint32(), C.c_int()
+        self._chk(self.lib.cg_cmp_scan(self.h, int(stopMatId), C.byref(a), C.byref(b), C.byref(f)))
+        return a.value, b.value, f.value
+
+    def cmp_apply(self, target_z, stopMatId):
+        self._chk(self.lib.cg_cmp_apply(self.h, float(target_z), int(stopMatId)))
+
+    def cavity_state(self):
+        """-> (has_gaps, has_cavity, max_len, top_q)."""
+        a, b, m, q = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
+        self._chk(self.lib.cg_cavity_state(self.h, C.byref(a), C.byref(b), C.byref(m), C.byref(q)))
+        return a.value, b.value, m.value, q.value
+
+    def cavity_fill(self, hmax_q):
+        self._chk(self.lib.cg_cavity_fill(self.h, int(hmax_q)))
+
+    def ghost_bytes(self, planes):
+        n = C.c_size_t()
+        self._chk(self.lib.cg_ghost_bytes(self.h, int(planes), C.byref(n)))
+        return n.value
+
+    def ghost_pack(self, planes, send_lower, send_upper):
+        self._chk(self.lib.cg_ghost_pack(self.h, int(planes), send_lower, send_upper))
+
+    def strip_seed(self, matId, planes, ghost_lower, ghost_upper):
+        self._chk(self.lib.cg_strip_seed(self.h, int(matId), int(planes), ghost_lower or None, ghost_upper or None))
+
+    def strip_sweep(self, matId, planes, ghost_lower, ghost_upper):
+        ch = C.c_int()
+        self._chk(self.lib.cg_strip_sweep(self.h, int(matId), int(planes), ghost_lower or None, ghost_upper or None, C.byref(ch)))
+        return ch.value
+
+    def strip_finish(self):
+        self._chk(self.lib.cg_strip_finish(self.h))
+
+    @property
+    def zScale(self):
+        return self.info().zscale
 
     # ---- etch_wet / deposit_ALD with the reference's anchors (sliderCache)
     @staticmethod

@@ -958,24 +958,43 @@ __global__ __launch_bounds__(256) void k_cmp_apply(GridView g, double targetZ, i
 // a < b - eps on de-quantised values is a < b on the integers.
 __device__ __forceinline__ unsigned z0_of(const GridView& g, size_t c, int k) { return k > 0 ? rec_z1(g.rec[(size_t)(k - 1) * g.N + c]) : 0u; }
 
+// A slab of a decomposed domain sees one row of its lower and of its upper neighbour as
+// "ghost" columns: len[ny] and rec[p*ny + j] for the planes exchanged (same record format, the
+// MARK bits included).  Null pointers = no neighbour on that side (the domain ends there).
+struct Ghost { const uint8_t* lo_len; const uint32_t* lo_rec; const uint8_t* up_len; const uint32_t* up_rec; int planes; };
+
+// Column (ni, nj) as seen from this slab: ok == false beyond the domain.
+struct ColRef { const uint32_t* rec; size_t stride; int len; bool ok; };
+__device__ __forceinline__ ColRef column_ref(const GridView& g, const Ghost& gh, int ni, int nj) {
+    ColRef r; r.rec = nullptr; r.stride = 0; r.len = 0; r.ok = false;
+    if (nj < 0 || nj >= g.ny) return r;
+    if (ni >= 0 && ni < g.nx) {
+        const size_t n = (size_t)ni * g.ny + nj;
+        r.rec = g.rec + n; r.stride = g.N; r.len = g.len[n]; r.ok = true;
+    } else if (ni == -1 && gh.lo_len) {
+        r.rec = gh.lo_rec + nj; r.stride = (size_t)g.ny; r.len = min((int)gh.lo_len[nj], gh.planes); r.ok = true;
+    } else if (ni == g.nx && gh.up_len) {
+        r.rec = gh.up_rec + nj; r.stride = (size_t)g.ny; r.len = min((int)gh.up_len[nj], gh.planes); r.ok = true;
+    }
+    return r;
+}
+
 // isExposed (cg1:882-905) for layer [z0q, z1q] of column (i, j)
-__device__ __forceinline__ bool layer_exposed(const GridView& g, int i, int j, unsigned z0q, unsigned z1q, unsigned topq) {
+__device__ __forceinline__ bool layer_exposed(const GridView& g, const Ghost& gh, int i, int j, unsigned z0q, unsigned z1q, unsigned topq) {
     if (z0q == 0) return false;                       // resting on the floor: not exposed
     if (z1q == topq) return true;                     // top of its column
     const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-        const int ni = i + di[d], nj = j + dj[d];
-        if (ni < 0 || ni >= g.nx || nj < 0 || nj >= g.ny) return false;      // the domain edge ends the scan (cg1:896)
-        const size_t n = (size_t)ni * g.ny + nj;
-        const int nl = g.len[n];
-        if (nl == 0) return true;
-        if (rec_z1(g.rec[(size_t)(nl - 1) * g.N + n]) < z1q) return true;
+        const ColRef n = column_ref(g, gh, i + di[d], j + dj[d]);
+        if (!n.ok) return false;                      // the domain edge ends the scan (cg1:896)
+        if (n.len == 0) return true;
+        if (rec_z1(n.rec[(size_t)(n.len - 1) * n.stride]) < z1q) return true;
     }
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_strip_seed(GridView g, int matId) {
+__global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh, int matId) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
@@ -985,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_strip_seed(GridView g, int matId) {
         unsigned prev = 0;
         for (int k = 0; k < l; k++) {
             const uint32_t r = g.rec[(size_t)k * g.N + c];
-            if (!rec_hole(r) && rec_mat(r) == matId && layer_exposed(g, i, j, prev, rec_z1(r), topq))
+            if (!rec_hole(r) && rec_mat(r) == matId && layer_exposed(g, gh, i, j, prev, rec_z1(r), topq))
                 g.rec[(size_t)k * g.N + c] = r | REC_MARK;
             prev = rec_z1(r);
         }
@@ -993,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_strip_seed(GridView g, int matId) {
 }
 
 // one relaxation sweep: an unmarked node next to an overlapping marked node becomes marked
-__global__ __launch_bounds__(256) void k_strip_flood(GridView g, int matId, int* __restrict__ changed) {
+__global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int matId, int* __restrict__ changed) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     int any = 0;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
@@ -1010,13 +1029,11 @@ __global__ __launch_bounds__(256) void k_strip_flood(GridView g, int matId, int*
             const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
 #pragma unroll
             for (int d = 0; d < 4 && !hit; d++) {
-                const int ni = i + di[d], nj = j + dj[d];
-                if (ni < 0 || ni >= g.nx || nj < 0 || nj >= g.ny) continue;
-                const size_t n = (size_t)ni * g.ny + nj;
-                const int nl = g.len[n];
+                const ColRef n = column_ref(g, gh, i + di[d], j + dj[d]);
+                if (!n.ok) continue;
                 unsigned b0 = 0;
-                for (int kk = 0; kk < nl; kk++) {
-                    const uint32_t rb = g.rec[(size_t)kk * g.N + n];
+                for (int kk = 0; kk < n.len; kk++) {
+                    const uint32_t rb = n.rec[(size_t)kk * n.stride];
                     const unsigned b1 = rec_z1(rb);
                     if ((rb & REC_MARK) && !rec_hole(rb) && rec_mat(rb) == matId && a0 < b1 && b0 < a1) { hit = true; break; }   // cg1:879
                     b0 = b1;
@@ -1027,6 +1044,23 @@ __global__ __launch_bounds__(256) void k_strip_flood(GridView g, int matId, int*
         }
     }
     if (any) *changed = 1;
+}
+
+// Boundary rows of a slab as ghost messages: len[ny] (padded to a multiple of 4 bytes), then
+// rec[planes][ny].  send_lower = row 0, send_upper = row nx-1.
+__global__ __launch_bounds__(256) void k_ghost_pack(GridView g, int planes, uint8_t* __restrict__ send_lower, uint8_t* __restrict__ send_upper) {
+    const size_t lenb = ((size_t)g.ny + 3) & ~(size_t)3;
+    const size_t n = (size_t)g.ny * (planes + 1);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+        const int p = (int)(e / g.ny) - 1, j = (int)(e % g.ny);
+        const size_t lo = j, hi = (size_t)(g.nx - 1) * g.ny + j;
+        if (p < 0) { send_lower[j] = g.len[lo]; send_upper[j] = g.len[hi]; }
+        else {
+            ((uint32_t*)(send_lower + lenb))[(size_t)p * g.ny + j] = p < (int)g.len[lo] ? g.rec[(size_t)p * g.N + lo] : 0u;
+            ((uint32_t*)(send_upper + lenb))[(size_t)p * g.ny + j] = p < (int)g.len[hi] ? g.rec[(size_t)p * g.N + hi] : 0u;
+        }
+    }
 }
 
 // removal + compaction (cg1:970-999): marked layers go; one in the middle of a column leaves a

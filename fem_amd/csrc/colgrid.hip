@@ -911,8 +911,9 @@ int cg_stencil_finish(cg_grid* g) {
     }
     std::swap(g->top, g->top_alt);
     if (g->len_bound < 255) g->len_bound += 1;
-    // identify_cavity (cg1:543) -- a no-op while no column has a vertical gap
-    if (g->has_gaps || g->has_cavity) return cg_identify_cavity(g);
+    // identify_cavity (cg1:543) -- a no-op while no column has a vertical gap.  On a slab the
+    // driver runs it over all slabs (the decision and the flood are whole-domain matters).
+    if ((g->has_gaps || g->has_cavity) && g->nx == g->nx_global) return cg_identify_cavity(g);
     return CG_OK;
 }
 
@@ -930,10 +931,9 @@ int cg_etch_general(cg_grid* g, int mask_id, int mat, double thickness, double c
     return cg_stencil_finish(g);
 }
 
-int cg_cmp(cg_grid* g, double depth, int stop_mat) {
+// ---- whole-column steps, in the pieces a decomposed domain needs between its exchanges ---------
+int cg_cmp_scan(cg_grid* g, int stop_mat, uint32_t* top_q, uint32_t* stopper_q, int* stopper_found) {
     NEED(g);
-    if (!(depth > 0)) return CG_OK;                                        // cg1:748
-    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "cmp on a slab of a decomposed domain is not built yet");
     if (stop_mat < 0 || stop_mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", stop_mat);
     g->pend.active = false;
     unsigned qtop = 0;
@@ -948,41 +948,143 @@ int cg_cmp(cg_grid* g, double depth, int stop_mat) {
         HIPCHK(g, hipMemcpyAsync(st, g->d_red + 2, sizeof st, hipMemcpyDeviceToHost, g->stream));
         HIPCHK(g, hipStreamSynchronize(g->stream));
     }
+    if (top_q) *top_q = qtop;
+    if (stopper_q) *stopper_q = st[0];
+    if (stopper_found) *stopper_found = st[1] ? 1 : 0;
+    return CG_OK;
+}
+
+int cg_cmp_apply(cg_grid* g, double target_z, int stop_mat) {
+    NEED(g);
+    if (stop_mat < 0 || stop_mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", stop_mat);
+    g->pend.active = false;
+    int rc = ensure_whole(g); if (rc) return rc;
+    ProfScope ps(g, CG_K_OTHER);
+    hipLaunchKernelGGL(k_cmp_apply, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), target_z, stop_mat);
+    HIPCHK(g, hipGetLastError());
+    return CG_OK;
+}
+
+int cg_cmp(cg_grid* g, double depth, int stop_mat) {
+    NEED(g);
+    if (!(depth > 0)) return CG_OK;                                        // cg1:748
+    if (g->nx != g->nx_global)
+        return fail(g, CG_ERR_UNSUPPORTED, "cmp on a slab needs the whole domain's heights: use cg_cmp_scan / cg_cmp_apply and reduce in between");
+    uint32_t qtop = 0, qstop = 0; int found = 0;
+    int rc = cg_cmp_scan(g, stop_mat, &qtop, &qstop, &found); if (rc) return rc;
     const double zTop = (double)qtop * g->zscale;                          // cg1:755-781
-    const double targetZ = (stop_mat == 0 || !st[1]) ? zTop - depth : std::max(zTop - depth, (double)st[0] * g->zscale);
-    {
-        ProfScope ps(g, CG_K_OTHER);
-        hipLaunchKernelGGL(k_cmp_apply, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), targetZ, stop_mat);
-        HIPCHK(g, hipGetLastError());
-    }
+    const double targetZ = (stop_mat == 0 || !found) ? zTop - depth : std::max(zTop - depth, (double)qstop * g->zscale);
+    rc = cg_cmp_apply(g, targetZ, stop_mat); if (rc) return rc;
     return cg_identify_cavity(g);                                          // cg1:858
 }
 
-int cg_strip_connected(cg_grid* g, int mat) {
+namespace {
+size_t ghost_len_bytes(const cg_grid* g) { return ((size_t)g->ny + 3) & ~(size_t)3; }
+Ghost make_ghost(const cg_grid* g, int planes, const void* lower, const void* upper) {
+    Ghost gh;
+    gh.planes = planes;
+    gh.lo_len = (const uint8_t*)lower; gh.lo_rec = lower ? (const uint32_t*)((const uint8_t*)lower + ghost_len_bytes(g)) : nullptr;
+    gh.up_len = (const uint8_t*)upper; gh.up_rec = upper ? (const uint32_t*)((const uint8_t*)upper + ghost_len_bytes(g)) : nullptr;
+    return gh;
+}
+}  // namespace
+
+int cg_ghost_bytes(const cg_grid* g, int planes, size_t* bytes) {
+    if (!g || !bytes || planes < 0) return CG_ERR_ARG;
+    *bytes = ghost_len_bytes(g) + (size_t)planes * g->ny * 4;
+    return CG_OK;
+}
+
+int cg_ghost_pack(cg_grid* g, int planes, void* send_lower, void* send_upper) {
     NEED(g);
-    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "strip_connected on a slab of a decomposed domain is not built yet");
+    if (planes < 0 || planes > 256 || !send_lower || !send_upper) return fail(g, CG_ERR_ARG, "bad ghost arguments");
+    int rc = ensure_whole(g); if (rc) return rc;
+    ProfScope ps(g, CG_K_HALO);
+    hipLaunchKernelGGL(k_ghost_pack, dim3(blocks_for((size_t)g->ny * (planes + 1))), dim3(256), 0, g->stream, view(g), planes,
+                       (uint8_t*)send_lower, (uint8_t*)send_upper);
+    HIPCHK(g, hipGetLastError());
+    return CG_OK;
+}
+
+int cg_strip_seed(cg_grid* g, int mat, int planes, const void* ghost_lower, const void* ghost_upper) {
+    NEED(g);
     if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
     g->pend.active = false;
-    { int rcw = ensure_whole(g); if (rcw) return rcw; }
+    int rc = ensure_whole(g); if (rc) return rc;
+    ProfScope ps(g, CG_K_OTHER);
+    hipLaunchKernelGGL(k_strip_seed, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), make_ghost(g, planes, ghost_lower, ghost_upper), mat);
+    HIPCHK(g, hipGetLastError());
+    return CG_OK;
+}
+
+int cg_strip_sweep(cg_grid* g, int mat, int planes, const void* ghost_lower, const void* ghost_upper, int* changed) {
+    NEED(g);
+    if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
+    if (g->split) return fail(g, CG_ERR_STATE, "cg_strip_sweep without cg_strip_seed");
     ProfScope ps(g, CG_K_OTHER);
     const dim3 grid(blocks_for(g->N)), blk(256);
-    hipLaunchKernelGGL(k_strip_seed, grid, blk, 0, g->stream, view(g), mat);
-    HIPCHK(g, hipGetLastError());
-    // relax to the fixpoint; the flag is read back once per batch of sweeps
+    const Ghost gh = make_ghost(g, planes, ghost_lower, ghost_upper);
+    int any = 0;
+    // relax to the local fixpoint; the flag is read back once per batch of sweeps
     for (int round = 0;; round++) {
         if (round > 1000000) return fail(g, CG_ERR_STATE, "strip_connected did not converge");
         HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
-        for (int sweep = 0; sweep < 4; sweep++) hipLaunchKernelGGL(k_strip_flood, grid, blk, 0, g->stream, view(g), mat, g->d_flags);
+        for (int sweep = 0; sweep < 4; sweep++) hipLaunchKernelGGL(k_strip_flood, grid, blk, 0, g->stream, view(g), gh, mat, g->d_flags);
         HIPCHK(g, hipGetLastError());
         int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
         if (!fl[0]) break;
+        any = 1;
     }
+    if (changed) *changed = any;
+    return CG_OK;
+}
+
+int cg_strip_finish(cg_grid* g) {
+    NEED(g);
+    if (g->split) return fail(g, CG_ERR_STATE, "cg_strip_finish without cg_strip_seed");
+    ProfScope ps(g, CG_K_OTHER);
     HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
-    hipLaunchKernelGGL(k_strip_compact, grid, blk, 0, g->stream, view(g), g->d_flags);
+    hipLaunchKernelGGL(k_strip_compact, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_flags);
     HIPCHK(g, hipGetLastError());
     int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
     g->has_gaps = fl[2] != 0;
     g->has_cavity = fl[1] != 0;
+    return CG_OK;
+}
+
+int cg_strip_connected(cg_grid* g, int mat) {
+    NEED(g);
+    if (g->nx != g->nx_global)
+        return fail(g, CG_ERR_UNSUPPORTED, "strip_connected on a slab crosses its edges: use cg_ghost_pack / cg_strip_seed / cg_strip_sweep / cg_strip_finish");
+    int rc = cg_strip_seed(g, mat, 0, nullptr, nullptr); if (rc) return rc;
+    rc = cg_strip_sweep(g, mat, 0, nullptr, nullptr, nullptr); if (rc) return rc;
+    return cg_strip_finish(g);
+}
+
+int cg_cavity_state(cg_grid* g, int* has_gaps, int* has_cavity, int* max_len, uint32_t* top_q) {
+    NEED(g);
+    unsigned q = 0;
+    int rc = refresh_len_bound(g, &q); if (rc) return rc;
+    if (has_gaps) *has_gaps = g->has_gaps ? 1 : 0;
+    if (has_cavity) *has_cavity = g->has_cavity ? 1 : 0;
+    if (max_len) *max_len = g->len_bound;
+    if (top_q) *top_q = q;
+    return CG_OK;
+}
+
+int cg_cavity_fill(cg_grid* g, uint32_t hmax_q) {
+    NEED(g);
+    g->pend.active = false;
+    int rc = ensure_whole(g); if (rc) return rc;
+    rc = refresh_len_bound(g, nullptr); if (rc) return rc;
+    if (g->len_bound >= g->lmax) { rc = grow_planes(g); if (rc) return rc; }       // room for the piece above every column
+    {
+        ProfScope ps(g, CG_K_OTHER);
+        hipLaunchKernelGGL(k_cavity_fill, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), (unsigned)hmax_q);
+        HIPCHK(g, hipGetLastError());
+    }
+    if (g->len_bound < 255) g->len_bound += 1;
+    g->has_cavity = true;
     return CG_OK;
 }
 
@@ -993,19 +1095,12 @@ int cg_identify_cavity(cg_grid* g) {
     // script_columngrid.js:891), and nothing else of material 2 exists that the flood could
     // reach: the grid is left exactly as it was.
     if (!g->has_gaps && !g->has_cavity) return CG_OK;
-    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "identify_cavity with gaps on a slab of a decomposed domain is not built yet");
-    g->pend.active = false;
+    if (g->nx != g->nx_global)
+        return fail(g, CG_ERR_UNSUPPORTED, "identify_cavity on a slab needs the whole domain: use cg_cavity_state / cg_cavity_fill and the cg_strip_* calls");
     unsigned qtop = 0;
-    int rc = ensure_whole(g); if (rc) return rc;
-    rc = refresh_len_bound(g, &qtop); if (rc) return rc;
-    if (g->len_bound >= g->lmax) { rc = grow_planes(g); if (rc) return rc; }       // room for the piece above every column
+    int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
     const unsigned hmax_q = qtop > 0 ? qtop : (unsigned)js_round(1.0 / g->zscale) & 0xffffu;        // maxHeight() is 1 for a flat-zero grid (cg2:103)
-    {
-        ProfScope ps(g, CG_K_OTHER);
-        hipLaunchKernelGGL(k_cavity_fill, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), hmax_q);
-        HIPCHK(g, hipGetLastError());
-    }
-    if (g->len_bound < 255) g->len_bound += 1;
+    rc = cg_cavity_fill(g, hmax_q); if (rc) return rc;
     return cg_strip_connected(g, CG_MAT_CAVITY);                                    // cg2:79
 }
 

@@ -170,7 +170,18 @@ def flow_cw():
     ]
 
 
-FLOWS = {"c1": flow_c1, "c2": flow_c2, "c3": flow_c3, "c4": flow_c4, "c5": flow_c5, "cw": flow_cw}
+def flow_cs():
+    """Not a benchmark configuration: gaps, enclosed cavities, STRIP and CMP with and without a
+    stopper, for the parity tests of the slab driver."""
+    return [
+        _s("SUBSTR", None, SI, 20), _s("DEPO", None, OX, 8), _s("DEPO", None, NIT, 12), _s("ETCH", "M", ALL, 25),
+        _s("STRIP", None, OX, 1), _s("DEPO", None, M6, 6, 1.0), _s("ETCH", "Mc", ALL, 30), _s("STRIP", None, OX, 1),
+        _s("DEPO", None, M7, 5, 1.0), _s("CMP", None, 0, 4), _s("ETCH", "Mshift", M7, 4, 1.0), _s("CMP", None, NIT, 30),
+        _s("STRIP", None, M6, 1), _s("DEPO", None, OX, 7, 1.0), _s("CMP", None, SI, 40), _s("DEPO", "M", NIT, 3, 0.8),
+    ]
+
+
+FLOWS = {"c1": flow_c1, "c2": flow_c2, "c3": flow_c3, "c4": flow_c4, "c5": flow_c5, "cw": flow_cw, "cs": flow_cs}
 
 
 def apply_step(grid, step, masks):

@@ -6,8 +6,11 @@ radius R reaches into the neighbouring slabs.  For those steps each rank
   1. snapshots its top heights (+ etchable flags)          grid.stencil_begin
   2. swaps R boundary rows with its two neighbours          torch.distributed send/recv (RCCL)
   3. runs the dilation / erosion and the column update      grid.stencil_finish
-Layer stacks never move between GPUs.  Whole-domain scalars (max height, checksum) are
-all-reduced.  The reference is single-threaded (template/script_columngrid.js); this file has
+Layer stacks never move between GPUs.  Whole-domain scalars (max height, checksum, CMP's
+target height, "is there any gap") are all-reduced.  strip_connected / identify_cavity flood
+across slab edges: each rank relaxes to its local fixpoint, swaps one boundary row (whole
+columns with their flood marks) with each neighbour, and the ranks stop when a round changed
+nothing anywhere.  The reference is single-threaded (template/script_columngrid.js); this file has
 no counterpart there.
 
 `grid` is any object with stencil_begin / stencil_finish / halo access in the style of
@@ -21,10 +24,34 @@ import torch.distributed as dist
 STENCIL_DEPOSIT, STENCIL_ETCH = 0, 1
 
 
+class TorchComm:
+    """Neighbour swaps and small all-reduces over torch.distributed (backend nccl = RCCL, or gloo)."""
+
+    def __init__(self, rank, world, device, group=None):
+        self.rank, self.world, self.device, self.group = rank, world, device, group
+
+    def swap(self, send_lower, send_upper, recv_lower, recv_upper):
+        """send_lower -> rank-1 (arrives as its recv_upper), send_upper -> rank+1 (its recv_lower)."""
+        ops = []
+        if self.rank > 0:
+            ops += [dist.P2POp(dist.isend, send_lower, self.rank - 1, self.group), dist.P2POp(dist.irecv, recv_lower, self.rank - 1, self.group)]
+        if self.rank < self.world - 1:
+            ops += [dist.P2POp(dist.isend, send_upper, self.rank + 1, self.group), dist.P2POp(dist.irecv, recv_upper, self.rank + 1, self.group)]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def reduce(self, values, op="max", dtype=torch.int64):
+        t = torch.tensor(list(values), dtype=dtype, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.group)
+        return t.tolist()
+
+
 class SlabGrid:
-    def __init__(self, grid, rank=0, world=1, device=None, group=None, dx=2.0, dy=2.0, ny=None, halo_rows=32):
+    def __init__(self, grid, rank=0, world=1, device=None, group=None, dx=2.0, dy=2.0, ny=None, halo_rows=32, comm=None):
         self.grid, self.rank, self.world, self.group = grid, rank, world, group
         self.device = device if device is not None else torch.device("cpu")
+        self.comm = comm if comm is not None else (TorchComm(rank, world, self.device, group) if world > 1 else None)
         self.dx, self.dy = dx, dy
         self.ny = ny if ny is not None else grid.NY
         self.has_lower, self.has_upper = rank > 0, rank < world - 1
@@ -49,15 +76,7 @@ class SlabGrid:
 
     def _exchange(self, R):
         n = R * self.ny * 3
-        s_lo, s_up, r_lo, r_up = [t[:n] for t in self._halo]
-        ops = []
-        if self.has_lower:
-            ops += [dist.P2POp(dist.isend, s_lo, self.rank - 1, self.group), dist.P2POp(dist.irecv, r_lo, self.rank - 1, self.group)]
-        if self.has_upper:
-            ops += [dist.P2POp(dist.isend, s_up, self.rank + 1, self.group), dist.P2POp(dist.irecv, r_up, self.rank + 1, self.group)]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        self.comm.swap(*[t[:n] for t in self._halo])
 
     def _step(self, kind, mask, mat, t, S):
         if self.world > 1:
@@ -71,9 +90,65 @@ class SlabGrid:
             self._exchange(R)
         self.grid.stencil_finish()
 
+    def _reduce_max(self, values):
+        return [int(v) for v in self.comm.reduce([int(v) for v in values], "max")]
+
+    def _swap_ghosts(self, nbytes):
+        """My row 0 becomes the lower neighbour's upper ghost, my last row the upper neighbour's lower ghost."""
+        self.comm.swap(*[t[:nbytes] for t in self._ghost])
+
     # ---- the reference's step names
     def deposit_general(self, mask, matId, thickness, conformality=1.0):
         self._step(STENCIL_DEPOSIT, mask, matId, thickness, conformality)
+        if self.world > 1 and self._radius(thickness, conformality) > 0:
+            self.identify_cavity()                       # script_columngrid.js:543; a slab handle leaves it to us
+
+    def strip_connected(self, matId):
+        """strip_connected(matId) (script_columngrid.js:867 - script_columngrid2.js:1) over all slabs."""
+        if self.world == 1:
+            return self.grid.strip_connected(matId)
+        g = self.grid
+        planes = self._reduce_max([g.cavity_state()[2]])[0]
+        nbytes = g.ghost_bytes(planes)
+        if getattr(self, "_ghost", None) is None or self._ghost[0].numel() < nbytes:
+            self._ghost = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(4)]
+        s_lo, s_up, r_lo, r_up = [t.data_ptr() for t in self._ghost]
+        lo, up = (r_lo if self.has_lower else 0), (r_up if self.has_upper else 0)
+        g.ghost_pack(planes, s_lo, s_up); g.sync(); self._swap_ghosts(nbytes)
+        g.strip_seed(matId, planes, lo, up)
+        g.ghost_pack(planes, s_lo, s_up); g.sync(); self._swap_ghosts(nbytes)
+        while True:
+            changed = g.strip_sweep(matId, planes, lo, up)
+            if not self._reduce_max([changed])[0]:
+                break
+            g.ghost_pack(planes, s_lo, s_up); g.sync(); self._swap_ghosts(nbytes)
+        g.strip_finish()
+
+    def identify_cavity(self):
+        """identify_cavity() (script_columngrid2.js:9-83) over all slabs."""
+        if self.world == 1:
+            return self.grid.identify_cavity()
+        gaps, cav, _, top_q = self.grid.cavity_state()
+        any_flag, top_q = self._reduce_max([1 if (gaps or cav) else 0, top_q])
+        if not any_flag:
+            return
+        zs = self.grid.zScale
+        hmax_q = top_q if top_q > 0 else int(math.floor(1.0 / zs + 0.5)) & 0xFFFF      # maxHeight() is 1 on an empty grid
+        self.grid.cavity_fill(hmax_q)
+        self.strip_connected(2)
+
+    def cmp(self, depth, stopMatId=0):
+        """cmp(depth, stopMatId) (script_columngrid.js:747-859) over all slabs."""
+        if self.world == 1:
+            return self.grid.cmp(depth, stopMatId)
+        if not depth > 0:
+            return
+        top_q, stop_q, found = self._reduce_max(self.grid.cmp_scan(stopMatId))
+        zs = self.grid.zScale
+        z_top = top_q * zs
+        target = z_top - depth if (stopMatId == 0 or not found) else max(z_top - depth, stop_q * zs)
+        self.grid.cmp_apply(target, stopMatId)
+        self.identify_cavity()
 
     def etch_general(self, mask, matId, thickness, conformality=1.0):
         self._step(STENCIL_ETCH, mask, matId, thickness, conformality)
@@ -85,17 +160,13 @@ class SlabGrid:
     def maxHeight(self):
         z = self.grid.maxHeight()
         if self.world > 1:
-            t = torch.tensor([z], dtype=torch.float64, device=self.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            z = float(t.item())
+            z = float(self.comm.reduce([z], "max", torch.float64)[0])
         return z
 
     def checksum(self):
         """Sum of the per-slab checksums mod 2^64 = checksum of the undivided grid."""
         s = self.grid.checksum()
         if self.world > 1:
-            parts = torch.tensor([s & 0xFFFFFFFF, s >> 32], dtype=torch.int64, device=self.device)
-            dist.all_reduce(parts, op=dist.ReduceOp.SUM, group=self.group)
-            lo, hi = int(parts[0].item()), int(parts[1].item())
+            lo, hi = [int(v) for v in self.comm.reduce([s & 0xFFFFFFFF, s >> 32], "sum")]
             s = (lo + (hi << 32)) & 0xFFFFFFFFFFFFFFFF
         return s

@@ -157,6 +157,30 @@ int cg_strip_connected(cg_grid* g, int mat);
 /* identify_cavity() (cg2:9-83). */
 int cg_identify_cavity(cg_grid* g);
 
+/* ---- cmp / strip_connected / identify_cavity in pieces, for a domain cut into slabs -------
+ * No counterpart in the reference (it is one array).  These steps need whole-domain scalars
+ * and a flood fill that crosses slab edges, so the driver (fem_amd/slabs.py) runs them as
+ *   cmp:              cg_cmp_scan on every slab, max-reduce (top_q, stopper_q, found),
+ *                     targetZ as cg1:781, cg_cmp_apply, then identify_cavity as below;
+ *   identify_cavity:  cg_cavity_state, OR-reduce the flags (nothing to do when both are clear
+ *                     everywhere), max-reduce top_q, cg_cavity_fill(hmax_q), strip of material 2;
+ *   strip_connected:  planes = max-reduced max_len; cg_ghost_pack + swap of one boundary row
+ *                     with each neighbour, cg_strip_seed, pack + swap again, then repeat
+ *                     { cg_strip_sweep; stop when no slab changed; pack + swap }, cg_strip_finish.
+ * A ghost message is len[ny] (padded to a multiple of 4 bytes) followed by rec[planes][ny]
+ * (u32 records, flood marks included); cg_ghost_bytes gives its size.  ghost_lower / ghost_upper
+ * are the messages received from the slab below / above, NULL where the domain ends.
+ * cg_cmp, cg_strip_connected and cg_identify_cavity are these pieces run on an undivided grid. */
+int cg_cmp_scan(cg_grid* g, int stop_mat, uint32_t* top_q, uint32_t* stopper_q, int* stopper_found);   /* cg1:755-781 */
+int cg_cmp_apply(cg_grid* g, double target_z, int stop_mat);                                          /* cg1:786-853 */
+int cg_cavity_state(cg_grid* g, int* has_gaps, int* has_cavity, int* max_len, uint32_t* top_q);
+int cg_cavity_fill(cg_grid* g, uint32_t hmax_q);                                                       /* cg2:23-71 */
+int cg_ghost_bytes(const cg_grid* g, int planes, size_t* bytes);
+int cg_ghost_pack(cg_grid* g, int planes, void* send_lower, void* send_upper);
+int cg_strip_seed(cg_grid* g, int mat, int planes, const void* ghost_lower, const void* ghost_upper);  /* cg1:910-929 */
+int cg_strip_sweep(cg_grid* g, int mat, int planes, const void* ghost_lower, const void* ghost_upper, int* changed);   /* cg1:934-965 */
+int cg_strip_finish(cg_grid* g);                                                                       /* cg1:970-999 */
+
 /* etch_wet(matId, totalThk, {dt}) without the slider cache (cg2:893 - cg3:308): isotropic
  * removal of `mat` (255 = every solid, id >= 3) in increments of dt nm, each followed by
  * identify_cavity.  total_thickness <= 0: no-op.  dt = NaN: the reference's default

@@ -524,7 +524,7 @@ int og_etch_general(og_grid *g, const uint8_t *mask, int matId, double t, double
 }
 
 /* Slab variants (test extension): the caller supplies the neighbours' rows; the trailing
- * identify_cavity of the conformal deposit is left to the caller (og_identify_cavity_hmax),
+ * identify_cavity of the conformal deposit is left to the caller (og_cavity_fill + a strip),
  * because its Hmax is a whole-domain maximum. */
 int og_deposit_general_halo(og_grid *g, const uint8_t *mask, int matId, double t, double S,
                             const float *lowerH, const float *upperH) {
@@ -701,12 +701,17 @@ static void og_identify_cavity_impl(og_grid *g, double Hmax_override, int use_ov
     }
     free(g->mat); free(g->zpair); free(g->len);
     g->mat = newMat; g->zpair = newZ; g->len = newLen;
-    og_strip_connected(g, CG_MAT_CAVITY);
+    if (use_override != 2) og_strip_connected(g, CG_MAT_CAVITY);
 }
+
+/* slab extension (tests of the multi-GPU driver): step 1 of identify_cavity alone, with the
+ * whole domain's maximum height given */
+int og_cavity_fill(og_grid *g, double Hmax) { og_identify_cavity_impl(g, Hmax, 2); return 0; }
 
 int og_identify_cavity(og_grid *g) { og_identify_cavity_impl(g, 0, 0); return 0; }
 
 /* ---- cmp, cg1:747-859 ------------------------------------------------------------------ */
+int og_cmp_apply(og_grid *g, double targetZ, int stopMatId);
 int og_cmp(og_grid *g, double depth, int stopMatId) {
     if (depth <= 0) return 0;
     int Lmax = g->Lmax; size_t Ncols = (size_t)g->NX * g->NY;
@@ -725,6 +730,14 @@ int og_cmp(og_grid *g, double depth, int stopMatId) {
     }
     double targetZ = (stopMatId == 0 || stopperTop == -INFINITY) ? zTop - depth
                                                                   : fmax(zTop - depth, stopperTop);
+    og_cmp_apply(g, targetZ, stopMatId);
+    og_identify_cavity_impl(g, 0, 0);
+    return 0;
+}
+
+/* the per-column part of cmp (cg1:786-853) for a given target height (slab extension) */
+int og_cmp_apply(og_grid *g, double targetZ, int stopMatId) {
+    int Lmax = g->Lmax; size_t Ncols = (size_t)g->NX * g->NY;
     for (size_t cidx = 0; cidx < Ncols; cidx++) {
         int len = g->len[cidx];
         if (len == 0) continue;
@@ -756,7 +769,6 @@ int og_cmp(og_grid *g, double depth, int stopMatId) {
             }
         }
     }
-    og_identify_cavity_impl(g, 0, 0);
     return 0;
 }
 

@@ -23,7 +23,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     nxl, ny = 40, 72
     nxg = nxl * world
-    flow = flows.flow_c4()
+    flow = flows.FLOWS[os.environ.get("SLAB_FLOW", "c4")]()
     specs = flows.mask_specs(2.0 * nxg)
     whole = OracleGrid(2.0 * nxg, 2.0 * ny, 2.0, 2.0)
     full_masks, my_masks = {}, {}

@@ -1,8 +1,10 @@
 """CPU stand-in for one rank's grid in the slab driver tests (test infrastructure only).
 
 It offers the same stencil_begin / stencil_finish / set_halo_buffers surface as
-fem_amd.ColumnGrid, implemented with the CPU oracle, and speaks the same halo wire format
-(R*ny u16 top heights followed by R*ny u8 etchable flags per direction)."""
+fem_amd.ColumnGrid, implemented with the CPU oracle, and speaks the same wire formats: halo =
+R*ny u16 top heights followed by R*ny u8 etchable flags per direction; ghost row = len[ny]
+(padded to 4 bytes) followed by rec[planes][ny] u32 records z1q | mat << 16 | flags << 24
+(flags: 1 gap, 2 flood mark, 8 layer), a gap being an interval of its own."""
 import ctypes
 import math
 
@@ -77,6 +79,178 @@ class OracleSlabEngine:
             self.o.etch_general_halo(mask, mat, t, S, lH, uH, lE, uE)
         else:
             self.o.deposit_general_halo(mask, mat, t, S, lH, uH)
+
+    # ---- cmp / identify_cavity / strip_connected in the pieces the slab driver calls -----------
+    zScale = 0.1
+
+    def sync(self):
+        pass
+
+    def _layers(self):
+        ln, mat, zp = self.o.arrays()
+        L = self.o.Lmax
+        return ln.astype(np.int64), mat.reshape(-1, L), zp.reshape(-1, L, 2).astype(np.int64), L
+
+    def cmp_scan(self, stop):
+        ln, mat, zp, L = self._layers()
+        top_q, stop_q, found = 0, 0, 0
+        for c in range(ln.size):
+            if ln[c]:
+                top_q = max(top_q, int(zp[c, ln[c] - 1, 1]))
+                if stop:
+                    for k in range(ln[c]):
+                        if mat[c, k] == stop:
+                            found = 1; stop_q = max(stop_q, int(zp[c, k, 1]))
+        return top_q, stop_q, found
+
+    def cmp_apply(self, target_z, stop):
+        self.o.L.og_cmp_apply.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
+        self.o.L.og_cmp_apply(self.o.h, float(target_z), int(stop))
+
+    def cavity_state(self):
+        ln, mat, zp, L = self._layers()
+        gaps = cav = 0; top_q = 0
+        for c in range(ln.size):
+            prev = 0
+            for k in range(ln[c]):
+                if zp[c, k, 0] > prev:
+                    gaps = 1
+                if mat[c, k] == 2:
+                    cav = 1
+                prev = zp[c, k, 1]
+            if ln[c]:
+                top_q = max(top_q, int(zp[c, ln[c] - 1, 1]))
+        return gaps, cav, int(ln.max()) * 2 + 1 if ln.size else 0, top_q      # gaps are intervals of their own on the wire
+
+    def cavity_fill(self, hmax_q):
+        self.o.L.og_cavity_fill.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        self.o.L.og_cavity_fill(self.o.h, float(hmax_q) * 0.1)
+
+    def ghost_bytes(self, planes):
+        return ((self.ny + 3) & ~3) + planes * self.ny * 4
+
+    def _intervals(self, c, ln, mat, zp, marks):
+        """Column c as the wire's intervals: [(z1q, mat, flags)], gaps included."""
+        out, prev = [], 0
+        for k in range(ln[c]):
+            if zp[c, k, 0] > prev:
+                out.append((int(zp[c, k, 0]), 0, 1))
+            fl = 8 | (2 if marks is not None and marks[c, k] else 0)
+            out.append((int(zp[c, k, 1]), int(mat[c, k]), fl))
+            prev = int(zp[c, k, 1])
+        return out
+
+    def ghost_pack(self, planes, send_lower, send_upper):
+        ln, mat, zp, L = self._layers()
+        marks = getattr(self, "_marks", None)
+        nb = self.ghost_bytes(planes); lenb = (self.ny + 3) & ~3
+        for ptr, row in ((send_lower, 0), (send_upper, self.nx - 1)):
+            buf = _view(ptr, nb); buf[:] = 0
+            rec = buf[lenb:].view(np.uint32).reshape(planes, self.ny)
+            for j in range(self.ny):
+                iv = self._intervals(row * self.ny + j, ln, mat, zp, marks)
+                buf[j] = len(iv)
+                for p, (z1, m, fl) in enumerate(iv[:planes]):
+                    rec[p, j] = z1 | (m << 16) | (fl << 24)
+
+    def _ghost_columns(self, planes, ptr):
+        """-> per j: [(z0, z1, mat, marked)] of the layers (gaps dropped), or None without a neighbour."""
+        if not ptr:
+            return None
+        nb = self.ghost_bytes(planes); lenb = (self.ny + 3) & ~3
+        buf = _view(ptr, nb)
+        rec = buf[lenb:].view(np.uint32).reshape(planes, self.ny)
+        cols = []
+        for j in range(self.ny):
+            prev, lay = 0, []
+            for p in range(min(int(buf[j]), planes)):
+                r = int(rec[p, j]); z1 = r & 0xFFFF; fl = r >> 24
+                if not (fl & 1):
+                    lay.append((prev, z1, (r >> 16) & 255, bool(fl & 2)))
+                prev = z1
+            cols.append(lay)
+        return cols
+
+    def _neighbour(self, i, j, own, lo, up):
+        """Layers [(z0, z1, mat, marked)] of column (i, j), or None beyond the domain."""
+        if j < 0 or j >= self.ny:
+            return None
+        if 0 <= i < self.nx:
+            return own[i * self.ny + j]
+        if i == -1 and lo is not None:
+            return lo[j]
+        if i == self.nx and up is not None:
+            return up[j]
+        return None
+
+    def _own_columns(self):
+        ln, mat, zp, L = self._layers()
+        return [[(int(zp[c, k, 0]), int(zp[c, k, 1]), int(mat[c, k]), bool(self._marks[c, k])) for k in range(ln[c])] for c in range(ln.size)]
+
+    def strip_seed(self, matId, planes, ghost_lower, ghost_upper):
+        ln, mat, zp, L = self._layers()
+        self._marks = np.zeros((ln.size, L), bool)
+        own = self._own_columns()
+        lo, up = self._ghost_columns(planes, ghost_lower), self._ghost_columns(planes, ghost_upper)
+        for i in range(self.nx):
+            for j in range(self.ny):
+                c = i * self.ny + j
+                for k, (z0, z1, m, _) in enumerate(own[c]):
+                    if m != matId or z0 == 0:
+                        continue
+                    exposed = z1 == own[c][-1][1]
+                    if not exposed:
+                        for di, dj in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                            nb = self._neighbour(i + di, j + dj, own, lo, up)
+                            if nb is None:
+                                break
+                            if not nb or nb[-1][1] < z1:
+                                exposed = True
+                                break
+                    self._marks[c, k] = exposed
+
+    def strip_sweep(self, matId, planes, ghost_lower, ghost_upper):
+        lo, up = self._ghost_columns(planes, ghost_lower), self._ghost_columns(planes, ghost_upper)
+        changed_any = 0
+        while True:
+            own = self._own_columns()
+            changed = False
+            for i in range(self.nx):
+                for j in range(self.ny):
+                    c = i * self.ny + j
+                    for k, (z0, z1, m, marked) in enumerate(own[c]):
+                        if m != matId or marked:
+                            continue
+                        for di, dj in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                            nb = self._neighbour(i + di, j + dj, own, lo, up)
+                            if nb and any(bm == matId and bk and z0 < b1 and b0 < z1 for (b0, b1, bm, bk) in nb):
+                                self._marks[c, k] = True; changed = True
+                                break
+            if not changed:
+                break
+            changed_any = 1
+        return changed_any
+
+    def strip_finish(self):
+        ln, mat, zp, L = self._layers()
+        nm = np.zeros_like(mat); nz = np.zeros_like(zp); nl = np.zeros_like(ln)
+        for c in range(ln.size):
+            w = 0
+            for k in range(ln[c]):
+                if not self._marks[c, k]:
+                    nm[c, w] = mat[c, k]; nz[c, w] = zp[c, k]; w += 1
+            nl[c] = w
+        self.o.upload(nl.astype(np.uint8), nm.reshape(-1), nz.astype(np.uint16).reshape(-1), L)
+        self._marks = None
+
+    def strip_connected(self, matId):
+        self.o.strip_connected(matId)
+
+    def identify_cavity(self):
+        self.o.identify_cavity()
+
+    def cmp(self, depth, stop=0):
+        self.o.cmp(depth, stop)
 
     def checksum(self):
         return self.o.checksum()

@@ -413,3 +413,88 @@ def test_slabs_on_one_gpu_equal_whole_grid(parts):
         assert total == whole.checksum() == o.checksum(), f"step {k} {st}"
     for s in slabs + [whole]:
         s.close()
+
+
+class _ThreadComm:
+    """fem_amd.slabs communicator for P ranks that are threads of one process (one GPU)."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def view(self, rank):
+        comm = self
+
+        class _Rank:
+            def swap(self, send_lower, send_upper, recv_lower, recv_upper):
+                import torch
+                torch.cuda.synchronize()
+                comm.slots[rank] = (send_lower, send_upper)
+                comm.barrier.wait()
+                if rank > 0:
+                    recv_lower.copy_(comm.slots[rank - 1][1])
+                if rank < comm.world - 1:
+                    recv_upper.copy_(comm.slots[rank + 1][0])
+                torch.cuda.synchronize()
+                comm.barrier.wait()
+
+            def reduce(self, values, op="max", dtype=None):
+                comm.slots[rank] = list(values)
+                comm.barrier.wait()
+                cols = list(zip(*comm.slots))
+                out = [max(c) if op == "max" else sum(c) for c in cols]
+                comm.barrier.wait()
+                return out
+
+        return _Rank()
+
+
+@pytest.mark.parametrize("parts,flow_name", [(2, "cs"), (3, "cs"), (3, "c4")])
+def test_slab_driver_on_one_gpu(parts, flow_name):
+    """fem_amd.slabs.SlabGrid itself (halo rows, all-reduced scalars, ghost-row flood of STRIP /
+    identify_cavity, CMP) with P slabs driven by P threads on one device: the summed checksum equals
+    the undivided grid's and the oracle's after every step."""
+    import threading
+    import torch
+    fem = _engine()
+    from fem_amd import flows
+    from fem_amd.slabs import SlabGrid
+    nxl, ny = 40, 72
+    nxg = nxl * parts
+    flow = flows.FLOWS[flow_name]()
+    specs = flows.mask_specs(2.0 * nxg)
+    o = OracleGrid(2.0 * nxg, 2.0 * ny, 2.0, 2.0)
+    names = sorted({s["mask"] for s in flow if s["mask"]})
+    reds = {n: fem.reduce_mask(flows.shapes_of(specs[n], 2 * nxg, 2 * ny)) for n in names}
+    om = {n: o.mask_raster(reds[n]) for n in names}
+    want = []
+    for st in flow:
+        flows.apply_step(o, st, om)
+        want.append((o.checksum(), o.max_height()))
+    comm = _ThreadComm(parts)
+    errors = []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            g = fem.ColumnGrid(dx=2.0, dy=2.0, slab=(nxg, ny, rank * nxl, nxl))
+            masks = {n: g.mask_from_shapes(reds[n]) for n in names}
+            slab = SlabGrid(g, rank, parts, device=torch.device("cuda", 0), ny=ny, halo_rows=4, comm=comm.view(rank))
+            for k, st in enumerate(flow):
+                flows.apply_step(slab, st, masks)
+                got = (slab.checksum(), slab.maxHeight())
+                if got != want[k]:
+                    raise AssertionError(f"rank {rank} step {k} {st}: {got} != {want[k]}")
+            g.close()
+        except BaseException as e:        # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(parts)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    assert not errors, errors[0]

@@ -29,6 +29,27 @@ __global__ __launch_bounds__(256) void k_mix(uint8_t* __restrict__ len, uint32_t
     }
 }
 
+// scattered append: the plane a group's old tops go to alternates every `run` groups (run*4 columns)
+template <int NPL>
+__global__ __launch_bounds__(256) void k_scatter(uint8_t* __restrict__ len, uint32_t* __restrict__ top, uint16_t* __restrict__ z0,
+                                                 uint32_t* __restrict__ planes, size_t n, int run, int halfgroup) {
+    const size_t ng = n / 4;
+    size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ng) return;
+    u8x4 ln = *(const u8x4*)(len + gi * 4); u32x4 tv = *(const u32x4*)(top + gi * 4);
+    const int p = (int)((gi / run) % NPL);
+    if (!halfgroup) *(u32x4*)(planes + (size_t)p * n + gi * 4) = tv;
+    else {   // the 4 columns of a group go to two different planes (2 + 2)
+        const int p2 = (p + 1) % NPL;
+        planes[(size_t)p * n + gi * 4] = tv[0]; planes[(size_t)p * n + gi * 4 + 1] = tv[1];
+        planes[(size_t)p2 * n + gi * 4 + 2] = tv[2]; planes[(size_t)p2 * n + gi * 4 + 3] = tv[3];
+    }
+    *(u32x4*)(top + gi * 4) = tv + 100u;
+    u16x4 z; z[0] = (unsigned short)tv[0]; z[1] = (unsigned short)tv[1]; z[2] = (unsigned short)tv[2]; z[3] = (unsigned short)tv[3];
+    *(u16x4*)(z0 + gi * 4) = z;
+    *(u8x4*)(len + gi * 4) = ln;
+}
+
 int main() {
     const size_t n = (size_t)16384 * 16384;
     uint8_t* len; uint32_t *top, *top2, *plane; uint16_t* z0;
@@ -51,5 +72,15 @@ int main() {
     RUN(2, 7, true, 4096, "R len+top, W plane+top+z0 (15 B/col)", 15.0);
     RUN(2, 1, true, 4096, "R len+top, W plane (9 B/col)", 9.0);
     RUN(2, 0, true, 4096, "R len+top only (5 B/col)", 5.0);
+    uint32_t* planes; CHK(hipMalloc(&planes, 4 * n * 4)); CHK(hipMemset(planes, 1, 4 * n * 4));
+#define RUNS(NPL, RUNLEN, HALF, NAME) time([&] { hipLaunchKernelGGL((k_scatter<NPL>), dim3((unsigned)(n / 4 / 256)), dim3(256), 0, 0, len, top, z0, planes, n, RUNLEN, HALF); }, NAME, 16.0)
+    RUNS(1, 1, 0, "append, one plane");
+    RUNS(2, 64, 0, "append, plane alternates every 256 columns");
+    RUNS(2, 8, 0, "append, plane alternates every 32 columns (128 B)");
+    RUNS(2, 4, 0, "append, plane alternates every 16 columns (64 B)");
+    RUNS(2, 2, 0, "append, plane alternates every 8 columns (32 B)");
+    RUNS(2, 1, 0, "append, plane alternates every 4 columns (16 B)");
+    RUNS(4, 2, 0, "append, 4 planes, every 8 columns");
+    RUNS(2, 1, 1, "append, plane alternates every 2 columns (8 B)");
     return 0;
 }
