@@ -4,9 +4,10 @@
  * The library keeps one process-emulation grid per handle resident in HBM and runs
  * every process step as hand-written HIP kernels.  The grid is a 2-D array of columns
  * (index c = i*NY + j, j fastest); every column is a stack of (material, z0, z1) layers.
- * On the device the stack is stored plane-major ("structure of arrays"):
- *     len[c] u8,   mat[k*N + c] u8,   z0[k*N + c] u16,   z1[k*N + c] u16
- * so that a wavefront touching layer k of 64 neighbouring columns reads contiguous bytes.
+ * On the device a column is len[c] (u8), its top interval top[c] (u32: z1 | material << 16 |
+ * flags << 24) with the bottom height topz0[c] (u16), and the rest of the stack plane-major,
+ * rec[k*N + c] (u32), so that a wavefront touching the tops -- or interval k -- of
+ * neighbouring columns reads contiguous bytes.
  * cg_download / cg_upload convert to and from the reference's host layout
  *     mat[c*Lmax + k],  zpair[2*(c*Lmax + k) + {0,1}],  len[c]
  * (reference: template/script_columngrid.js:84-86, 111-112).
