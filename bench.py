@@ -32,6 +32,8 @@ def parse():
     ap.add_argument("--flow", default="c4", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--cpu-n", type=int, default=2048, help="grid side of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-replicas", type=int, default=16, help="processes of the all-cores CPU baseline (0 = skip it)")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -78,8 +80,29 @@ def cpu_baseline(flows, flow, n):
                       f"masks pre-rasterised, {dt:.1f} s"}
 
 
+def cpu_baseline_all_cores(args, nproc):
+    """The same CPU sample as `nproc` independent replicas, one process each (the restatement is
+    single-threaded; columns of different grids are independent, so this is what all cores give)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--flow", args.flow, "--cpu-n", str(args.cpu_n)]
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(nproc)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    dt = time.perf_counter() - t0
+    if any(p.returncode for p in procs):
+        raise RuntimeError("a CPU replica failed")
+    per = [json.loads(o.strip().splitlines()[-1])["value"] for o in outs]
+    return {"value": sum(per), "unit": "Gcol/s", "cores": nproc, "kind": "port",
+            "sample": f"{nproc} independent replicas of the {args.cpu_n}x{args.cpu_n} sample, one single-threaded process each, "
+                      f"sum of their rates, {dt:.1f} s wall"}
+
+
 def main():
     args = parse()
+    if args.cpu_worker:                      # child of cpu_baseline_all_cores: CPU only, never touches the GPU
+        from fem_amd import flows as _flows
+        print(json.dumps(cpu_baseline(_flows, _flows.FLOWS[args.flow](), args.cpu_n)), flush=True)
+        return
     import torch
     import torch.distributed as dist
     import fem_amd
@@ -207,6 +230,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(flows, flow, args.cpu_n)
             except Exception as e:  # the baseline is a reported extra, never the measured path
                 out["cpu_baseline"] = {"value": None, "unit": "Gcol/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+            if args.cpu_replicas > 0 and world == 1:
+                try:
+                    out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args, args.cpu_replicas)
+                except Exception as e:
+                    out["cpu_baseline_all_cores"] = {"value": None, "unit": "Gcol/s", "cores": args.cpu_replicas, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
     grid.close()
     if world > 1:

@@ -351,10 +351,13 @@ class ColumnGrid:
     def cmp_apply(self, target_z, stopMatId):
         self._chk(self.lib.cg_cmp_apply(self.h, float(target_z), int(stopMatId)))
 
-    def cavity_state(self):
-        """-> (has_gaps, has_cavity, max_len, top_q)."""
+    def cavity_state(self, flags_only=False):
+        """-> (has_gaps, has_cavity, max_len, top_q); flags_only skips the reduction behind the last two."""
         a, b, m, q = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
-        self._chk(self.lib.cg_cavity_state(self.h, C.byref(a), C.byref(b), C.byref(m), C.byref(q)))
+        if flags_only:
+            self._chk(self.lib.cg_cavity_state(self.h, C.byref(a), C.byref(b), None, None))
+        else:
+            self._chk(self.lib.cg_cavity_state(self.h, C.byref(a), C.byref(b), C.byref(m), C.byref(q)))
         return a.value, b.value, m.value, q.value
 
     def cavity_fill(self, hmax_q):

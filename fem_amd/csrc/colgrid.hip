@@ -1064,7 +1064,7 @@ int cg_strip_connected(cg_grid* g, int mat) {
 int cg_cavity_state(cg_grid* g, int* has_gaps, int* has_cavity, int* max_len, uint32_t* top_q) {
     NEED(g);
     unsigned q = 0;
-    int rc = refresh_len_bound(g, &q); if (rc) return rc;
+    if (max_len || top_q) { int rc = refresh_len_bound(g, &q); if (rc) return rc; }      // the flags alone cost nothing
     if (has_gaps) *has_gaps = g->has_gaps ? 1 : 0;
     if (has_cavity) *has_cavity = g->has_cavity ? 1 : 0;
     if (max_len) *max_len = g->len_bound;

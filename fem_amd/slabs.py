@@ -128,10 +128,10 @@ class SlabGrid:
         """identify_cavity() (script_columngrid2.js:9-83) over all slabs."""
         if self.world == 1:
             return self.grid.identify_cavity()
-        gaps, cav, _, top_q = self.grid.cavity_state()
-        any_flag, top_q = self._reduce_max([1 if (gaps or cav) else 0, top_q])
-        if not any_flag:
+        gaps, cav, _, _ = self.grid.cavity_state(flags_only=True)
+        if not self._reduce_max([1 if (gaps or cav) else 0])[0]:
             return
+        top_q = self._reduce_max([self.grid.cavity_state()[3]])[0]
         zs = self.grid.zScale
         hmax_q = top_q if top_q > 0 else int(math.floor(1.0 / zs + 0.5)) & 0xFFFF      # maxHeight() is 1 on an empty grid
         self.grid.cavity_fill(hmax_q)

@@ -107,7 +107,7 @@ class OracleSlabEngine:
         self.o.L.og_cmp_apply.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int]
         self.o.L.og_cmp_apply(self.o.h, float(target_z), int(stop))
 
-    def cavity_state(self):
+    def cavity_state(self, flags_only=False):
         ln, mat, zp, L = self._layers()
         gaps = cav = 0; top_q = 0
         for c in range(ln.size):
