@@ -32,7 +32,10 @@ struct GridView {
     uint32_t* top;      // split form: the top interval of every column (0 for an empty column)
     uint32_t* top_w;    // where updated tops are stored: top itself, or the other buffer in a lateral step
     uint16_t* topz0;    // split form: its bottom height
-    int       split;    // 1: top interval in top/topz0, planes hold intervals 0..len-2; 0: planes hold all
+    uint8_t*  link;     // split form: plane that holds the interval below the top (len >= 2)
+    uint8_t*  prv;      // split form: prv[p*N + c] = plane of the interval below the one stored in plane p
+    int       P;        // split form: the plane this launch pushes old tops into (-1: it cannot append)
+    int       split;    // 1: split form (see below); 0: whole form, planes hold intervals 0..len-1 by index
     size_t    N;        // columns of this handle
     int       nx, ny;
     int       lmax;     // planes provisioned
@@ -90,23 +93,35 @@ __device__ __forceinline__ uint16_t quantz(double z, double zs, double inv_zs) {
 // All of them work on the split form of a column (GridView::split): the top interval in
 // top[c] / topz0[c], intervals 0 .. len-2 in the planes.
 
-// interval k of a column of length l, whichever form the grid is in (read-only kernels)
-__device__ __forceinline__ uint32_t col_rec(const GridView& g, size_t c, int k, int l) {
-    return (g.split && k == l - 1) ? g.top[c] : g.rec[(size_t)k * g.N + c];
+// All l intervals of a column bottom-up into out[], whichever form the grid is in (read-only kernels).
+__device__ __forceinline__ void load_column(const GridView& g, size_t c, int l, uint32_t* out) {
+    if (!g.split) { for (int k = 0; k < l; k++) out[k] = g.rec[(size_t)k * g.N + c]; return; }
+    if (l <= 0) return;
+    out[l - 1] = g.top[c];
+    int p = g.link[c];
+    for (int k = l - 2; k >= 0; k--) {
+        out[k] = g.rec[(size_t)p * g.N + c];
+        if (k > 0) p = g.prv[(size_t)p * g.N + c];
+    }
 }
 
-// The column has just lost its top; l intervals remain (l >= 1).  Loads the new top from its
-// plane, drops it too if it is a gap (a gap is never on top), and looks up the new bottom.
-__device__ __forceinline__ void reload_top(const GridView& g, size_t c, int& l, uint32_t& r, unsigned& z0q) {
-    r = g.rec[(size_t)(l - 1) * g.N + c];
-    uint32_t b = l > 1 ? g.rec[(size_t)(l - 2) * g.N + c] : 0;
+// The column has just lost its top; l intervals remain (l >= 1) and lk is the plane of the
+// topmost of them.  Loads the new top, drops it too if it is a gap (a gap is never on top), and
+// looks up the new bottom and the new link.
+__device__ __forceinline__ void reload_top(const GridView& g, size_t c, int& l, uint32_t& r, unsigned& z0q, int& lk) {
+    r = g.rec[(size_t)lk * g.N + c];
+    int p2 = l > 1 ? g.prv[(size_t)lk * g.N + c] : 0;
+    uint32_t b = l > 1 ? g.rec[(size_t)p2 * g.N + c] : 0;
     if (rec_hole(r)) {
         l -= 1;
         if (l == 0) { r = 0; z0q = 0; return; }
         r = b;
-        b = l > 1 ? g.rec[(size_t)(l - 2) * g.N + c] : 0;
+        const int p3 = l > 1 ? g.prv[(size_t)p2 * g.N + c] : 0;
+        b = l > 1 ? g.rec[(size_t)p3 * g.N + c] : 0;
+        p2 = p3;
     }
     z0q = rec_z1(b);
+    lk = p2;
 }
 
 // _depoAtTop_ (script_columngrid.js:397-426) for one column.  `l` is the column's current
@@ -119,7 +134,11 @@ __device__ __forceinline__ int depo_at_top(const GridView& g, size_t c, int l, i
     const uint16_t q = quantz((double)topq * g.zs + dz, g.zs, g.inv_zs);
     if (l > 0 && rec_mat(r) == matId) { g.top_w[c] = rec_with_z1(r, q); return 1; }
     if (l >= g.lmax) return 3;
-    if (l > 0) g.rec[(size_t)(l - 1) * g.N + c] = r;           // the old top takes its place in the stack
+    if (l > 0) {                                               // the old top goes into this step's plane
+        g.rec[(size_t)g.P * g.N + c] = r;
+        g.prv[(size_t)g.P * g.N + c] = g.link[c];
+        g.link[c] = (uint8_t)g.P;
+    }
     g.top_w[c] = rec_make(q, matId);                           // another material below: RUN stays clear
     g.topz0[c] = (uint16_t)topq;
     g.len[c] = (uint8_t)(l + 1);
@@ -148,12 +167,13 @@ __device__ __forceinline__ int apply_etch_at(const GridView& g, size_t c, int l,
     int removed = 0; bool touched = false;
     const int l0 = l;
     uint32_t r = g.top[c]; unsigned z0q = g.topz0[c];
+    int lk = l > 1 ? g.link[c] : 0;
     while (etch_round(g, r, z0q, l, remaining, matId, isAll, touched, removed)) {
-        if (l > 0) reload_top(g, c, l, r, z0q); else { r = 0; z0q = 0; }
+        if (l > 0) reload_top(g, c, l, r, z0q, lk); else { r = 0; z0q = 0; }
     }
     if (touched) {
         g.top_w[c] = r;
-        if (l != l0) { g.topz0[c] = (uint16_t)z0q; g.len[c] = (uint8_t)l; }
+        if (l != l0) { g.topz0[c] = (uint16_t)z0q; g.len[c] = (uint8_t)l; g.link[c] = (uint8_t)lk; }
     }
     return (touched ? 0x10000 : 0) | removed;
 }
@@ -165,21 +185,24 @@ __device__ __forceinline__ int apply_etch_at(const GridView& g, size_t c, int l,
 __device__ __forceinline__ double floor_of_top_run(const GridView& g, size_t c, int l, int matId, uint32_t r, unsigned z0q, unsigned& scanned) {
     scanned++;
     if (!(r & REC_RUN)) return (double)z0q * g.zs;
-    int s = l - 1;                 // interval whose bottom is the current floor
-    while (s > 0) {
-        uint32_t b = g.rec[(size_t)(s - 1) * g.N + c];
-        int nb = s - 1;
+    int m = l - 1;                 // intervals below the run found so far; p = plane of the topmost of them
+    int p = m > 0 ? g.link[c] : 0;
+    while (m > 0) {
+        const uint32_t b = g.rec[(size_t)p * g.N + c];
         if (rec_hole(b)) {         // look through the gap at the layer under it
-            if (nb == 0) break;
-            uint32_t b2 = g.rec[(size_t)(nb - 1) * g.N + c];
+            if (m == 1) break;
+            const int p2 = g.prv[(size_t)p * g.N + c];
+            const uint32_t b2 = g.rec[(size_t)p2 * g.N + c];
             if (rec_mat(b2) != matId) break;
-            s = nb - 1; scanned++;
+            m -= 2; scanned++;
+            if (m > 0) p = g.prv[(size_t)p2 * g.N + c];
             continue;
         }
         if (rec_mat(b) != matId) break;
-        s = nb; scanned++;
+        m -= 1; scanned++;
+        if (m > 0) p = g.prv[(size_t)p * g.N + c];
     }
-    return s > 0 ? (double)rec_z1(g.rec[(size_t)(s - 1) * g.N + c]) * g.zs : 0.0;
+    return m > 0 ? (double)rec_z1(g.rec[(size_t)p * g.N + c]) * g.zs : 0.0;
 }
 
 // block-wide accumulation of statistics into global counters
@@ -253,11 +276,11 @@ __device__ __forceinline__ u16x4 ld_u16x4(const uint16_t* p) { return *(const u1
 __device__ __forceinline__ void st_u16x4(uint16_t* p, u16x4 v) { *(u16x4*)p = v; }
 __device__ __forceinline__ unsigned open_bits(u8x4 mk) { return (mk[0] ? 1u : 0u) | (mk[1] ? 2u : 0u) | (mk[2] ? 4u : 0u) | (mk[3] ? 8u : 0u); }
 
-// _depoAtTop_ on the open columns of a group: column j grows by dz[j] (> 0).  tv = the 4 tops.
-// Returns whether the group's tops were stored.
+// _depoAtTop_ on the open columns of a group: column j grows by dz[j] (> 0).  tv = the 4 tops,
+// lk = their links.  Returns whether the group's tops were stored.
 template <bool STATS>
 __device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
-                                            u32x4 tv, int* __restrict__ flags, unsigned& n_ext, unsigned& n_app) {
+                                            u32x4 tv, u8x4 lk, int* __restrict__ flags, unsigned& n_ext, unsigned& n_app) {
     u32x4 nv = tv; u8x4 nl = ln;
     unsigned ext = 0, app = 0;
 #pragma unroll
@@ -272,23 +295,27 @@ __device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsign
     }
     if (!(ext | app)) return false;
     if (app) {
-        // the old tops move into the stack
-        const int l0 = ln[0];
-        if (app == 15u && as_u32(ln) == as_u32(splat4(l0))) { if (l0 > 0) st_rec4(g.rec + (size_t)(l0 - 1) * g.N + c0, tv); }
-        else {
+        // the old tops go into this step's plane (whatever the column lengths: one dense line per
+        // 32 columns), each with the link to what was below it
+        const size_t b = (size_t)g.P * g.N + c0;
+        u16x4 z; u8x4 nk = lk;
+        if (app == 15u) {
+            st_rec4(g.rec + b, tv);
+            st_u8x4(g.prv + b, lk);
 #pragma unroll
-            for (int j = 0; j < 4; j++) if (((app >> j) & 1) && ln[j] > 0) g.rec[(size_t)(ln[j] - 1) * g.N + c0 + j] = tv[j];
-        }
-        u16x4 z;
-        if (app == 15u) { z[0] = (unsigned short)rec_z1(ln[0] ? tv[0] : 0); z[1] = (unsigned short)rec_z1(ln[1] ? tv[1] : 0);
-                          z[2] = (unsigned short)rec_z1(ln[2] ? tv[2] : 0); z[3] = (unsigned short)rec_z1(ln[3] ? tv[3] : 0); }
-        else {
+            for (int j = 0; j < 4; j++) { z[j] = (unsigned short)rec_z1(ln[j] ? tv[j] : 0); if (ln[j]) nk[j] = (uint8_t)g.P; }
+        } else {
             z = ld_u16x4(g.topz0 + c0);
 #pragma unroll
-            for (int j = 0; j < 4; j++) if ((app >> j) & 1) z[j] = (unsigned short)rec_z1(ln[j] ? tv[j] : 0);
+            for (int j = 0; j < 4; j++) {
+                if (!((app >> j) & 1)) continue;
+                z[j] = (unsigned short)rec_z1(ln[j] ? tv[j] : 0);
+                if (ln[j]) { g.rec[b + j] = tv[j]; g.prv[b + j] = lk[j]; nk[j] = (uint8_t)g.P; }
+            }
         }
         st_u16x4(g.topz0 + c0, z);
         st_u8x4(g.len + c0, nl);
+        st_u8x4(g.link + c0, nk);
         if (STATS) n_app += __popc(app);
     }
     st_rec4(g.top_w + c0, nv);
@@ -297,12 +324,14 @@ __device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsign
 }
 
 // _applyEtchAt on the open columns of a group: column j loses dz[j] (> 0) from the top.
-// tv / zv = the 4 tops and their bottoms.  A column that loses its whole top layer reloads the
-// next one from the planes; columns doing so at the same length share the vector loads.
+// tv / zv / lkv = the 4 tops, their bottoms and their links.  A column that loses its whole top
+// layer reloads the next one through its link; columns whose links name the same plane (they were
+// pushed by the same step) share the vector loads.
 template <bool STATS>
 __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
-                                            bool isAll, u32x4 tv, u16x4 zv, unsigned& n_touched, unsigned& n_removed) {
+                                            bool isAll, u32x4 tv, u16x4 zv, u8x4 lkv, unsigned& n_touched, unsigned& n_removed) {
     int l[4] = {ln[0], ln[1], ln[2], ln[3]};
+    int lk[4] = {lkv[0], lkv[1], lkv[2], lkv[3]};
     uint32_t r[4] = {tv[0], tv[1], tv[2], tv[3]};
     unsigned z0[4] = {zv[0], zv[1], zv[2], zv[3]};
     double rem[4] = {dz[0], dz[1], dz[2], dz[3]};
@@ -317,22 +346,36 @@ __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsign
     }
     while (need) {
         const int j0 = __ffs(need) - 1;
-        const int L = l[j0];                                   // intervals left; the new top is interval L-1
+        const int p = lk[j0];                                  // plane of the new tops of this pass
         unsigned sel = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (((need >> j) & 1) && l[j] == L) sel |= 1u << j;
+        for (int j = 0; j < 4; j++) if (((need >> j) & 1) && lk[j] == p) sel |= 1u << j;
         need &= ~sel;
-        const u32x4 A = ld_rec4(g.rec + (size_t)(L - 1) * g.N + c0);
-        const u32x4 B = L > 1 ? ld_rec4(g.rec + (size_t)(L - 2) * g.N + c0) : (u32x4)(0);
+        const u32x4 A = ld_rec4(g.rec + (size_t)p * g.N + c0);
+        const u8x4 PV = ld_u8x4(g.prv + (size_t)p * g.N + c0);
+        // the intervals below the new tops (for their bottoms): one vector load when they share a plane
+        int p2 = -1; bool same = true;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (((sel >> j) & 1) && l[j] > 1) { if (p2 < 0) p2 = PV[j]; else if (PV[j] != p2) same = false; }
+        u32x4 B = (u32x4)(0);
+        if (p2 >= 0 && same) B = ld_rec4(g.rec + (size_t)p2 * g.N + c0);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (!((sel >> j) & 1)) continue;
-            r[j] = A[j]; z0[j] = rec_z1(B[j]);
-            if (rec_hole(A[j])) {                              // a gap under the removed layer goes with it
-                l[j] = L - 1;
-                if (l[j] > 0) { r[j] = B[j]; z0[j] = l[j] > 1 ? rec_z1(g.rec[(size_t)(l[j] - 2) * g.N + c0 + j]) : 0; }
-                else { r[j] = 0; z0[j] = 0; }
+            r[j] = A[j];
+            int q2 = PV[j];
+            uint32_t b = 0;
+            if (l[j] > 1) b = same ? B[j] : g.rec[(size_t)q2 * g.N + c0 + j];
+            if (rec_hole(r[j])) {                              // a gap under the removed layer goes with it
+                l[j] -= 1;
+                if (l[j] > 0) {
+                    r[j] = b;
+                    const int q3 = l[j] > 1 ? g.prv[(size_t)q2 * g.N + c0 + j] : 0;
+                    b = l[j] > 1 ? g.rec[(size_t)q3 * g.N + c0 + j] : 0;
+                    q2 = q3;
+                } else { r[j] = 0; b = 0; }
             }
+            z0[j] = rec_z1(b); lk[j] = q2;
             bool t = false; int rm = 0;
             if (etch_round(g, r[j], z0[j], l[j], rem[j], matId, isAll, t, rm)) { if (l[j] > 0) need |= 1u << j; else { r[j] = 0; z0[j] = 0; } }
             if (STATS) n_removed += rm;
@@ -344,8 +387,10 @@ __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsign
         if (popped) {
             u16x4 nz; nz[0] = (unsigned short)z0[0]; nz[1] = (unsigned short)z0[1]; nz[2] = (unsigned short)z0[2]; nz[3] = (unsigned short)z0[3];
             u8x4 nl; nl[0] = (uint8_t)l[0]; nl[1] = (uint8_t)l[1]; nl[2] = (uint8_t)l[2]; nl[3] = (uint8_t)l[3];
+            u8x4 nk; nk[0] = (uint8_t)lk[0]; nk[1] = (uint8_t)lk[1]; nk[2] = (uint8_t)lk[2]; nk[3] = (uint8_t)lk[3];
             st_u16x4(g.topz0 + c0, nz);
             st_u8x4(g.len + c0, nl);
+            st_u8x4(g.link + c0, nk);
         }
     }
     if (STATS) n_touched += __popc(dirty);
@@ -374,16 +419,17 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
         if (tile >= ntiles) continue;
         if (row_tiles > 1) { const size_t r = tile / row_tiles, q = tile - r * row_tiles; tile = r * row_tiles + (q + r) % row_tiles; }
         const size_t gbase = tile * tile_groups + threadIdx.x;
-        u8x4 ln[U]; unsigned open[U]; u32x4 tv[U]; u16x4 zv[U];
+        u8x4 ln[U], lk[U]; unsigned open[U]; u32x4 tv[U]; u16x4 zv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t gi = gbase + (size_t)u * 256;
-            open[u] = 0; ln[u] = splat4(0); tv[u] = (u32x4)(0); zv[u] = (u16x4)(0);
+            open[u] = 0; ln[u] = splat4(0); lk[u] = splat4(0); tv[u] = (u32x4)(0); zv[u] = (u16x4)(0);
             if (gi < ngroups) {
                 const size_t c0 = gi << 2;
                 open[u] = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
                 if (open[u]) {
                     ln[u] = ld_u8x4(g.len + c0);
+                    lk[u] = ld_u8x4(g.link + c0);
                     tv[u] = ld_rec4(g.top + c0);
                     if (ETCH) zv[u] = ld_u16x4(g.topz0 + c0);
                 }
@@ -394,8 +440,8 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
             if (!open[u]) continue;
             const size_t c0 = (gbase + (size_t)u * 256) << 2;
             if (STATS) loc[0] += __popc(open[u]);
-            if (ETCH) etch_group4<STATS>(g, c0, open[u], ln[u], dz, matId, isAll, tv[u], zv[u], loc[1], loc[2]);
-            else depo_group4<STATS>(g, c0, open[u], ln[u], dz, matId, tv[u], flags, loc[1], loc[2]);
+            if (ETCH) etch_group4<STATS>(g, c0, open[u], ln[u], dz, matId, isAll, tv[u], zv[u], lk[u], loc[1], loc[2]);
+            else depo_group4<STATS>(g, c0, open[u], ln[u], dz, matId, tv[u], lk[u], flags, loc[1], loc[2]);
         }
     }
     if (STATS) {
@@ -751,6 +797,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
 #undef CG_ADD
             // ---- per-column update
             const u8x4 ln = ld_u8x4(g.len + c0);
+            const u8x4 lkv = ld_u8x4(g.link + c0);
             double dz[4] = {0, 0, 0, 0};
             unsigned open = 0;
             if (STATS) loc[0] += __popc(act);
@@ -761,7 +808,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                     const double d = (double)m[c] - (double)own[c];          // cg1:534-537
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) stored = depo_group4<STATS>(g, c0, open, ln, dz, matId, tv, flags, loc[1], loc[2]);
+                if (open) stored = depo_group4<STATS>(g, c0, open, ln, dz, matId, tv, lkv, flags, loc[1], loc[2]);
             } else {
                 const u16x4 zv = ld_u16x4(g.topz0 + c0);
 #pragma unroll
@@ -774,7 +821,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                     const double d = (double)own[c] - (double)hpv;
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) stored = etch_group4<STATS>(g, c0, open, ln, dz, matId, isAll, tv, zv, loc[1], loc[2]);
+                if (open) stored = etch_group4<STATS>(g, c0, open, ln, dz, matId, isAll, tv, zv, lkv, loc[1], loc[2]);
             }
         }
         if (!stored && g.top_w != g.top) st_rec4(g.top_w + c0, tv);       // columns that stay as they are
@@ -849,7 +896,10 @@ __global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restric
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         int l = g.len[c];
-        if (l > 0) { unsigned q = rec_z1(col_rec(g, c, l - 1, l)); mq = q > mq ? q : mq; ml = (unsigned)l > ml ? (unsigned)l : ml; }
+        if (l > 0) {
+            const unsigned q = rec_z1(g.split ? g.top[c] : g.rec[(size_t)(l - 1) * g.N + c]);
+            mq = q > mq ? q : mq; ml = (unsigned)l > ml ? (unsigned)l : ml;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         unsigned a = __shfl_down(mq, o, 64), b = __shfl_down(ml, o, 64);
@@ -872,14 +922,16 @@ __global__ __launch_bounds__(256) void k_checksum(GridView g, unsigned long long
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         unsigned long long gc = (unsigned long long)g.i0 * g.ny + c;
-        const int l = min((int)g.len[c], g.lmax);
+        const int l = g.len[c];
+        uint32_t col[256];
+        load_column(g, c, l, col);
         int layers = 0;
-        for (int k = 0; k < l; k++) layers += !rec_hole(col_rec(g, c, k, l));
+        for (int k = 0; k < l; k++) layers += !rec_hole(col[k]);
         unsigned long long h = splitmix64(gc);
         h = splitmix64(h ^ (unsigned long long)layers);
         unsigned prev = 0;
         for (int k = 0; k < l; k++) {
-            const uint32_t r = col_rec(g, c, k, l);
+            const uint32_t r = col[k];
             if (!rec_hole(r)) {
                 unsigned long long v = (unsigned long long)rec_mat(r) | ((unsigned long long)prev << 8) | ((unsigned long long)rec_z1(r) << 24);
                 h = splitmix64(h ^ v);
@@ -1125,10 +1177,12 @@ __global__ __launch_bounds__(256) void k_gather_columns(GridView g, size_t col0,
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < ncols; s += stride) {
         const size_t c = col0 + s * col_stride;
-        const int l = min((int)g.len[c], g.lmax);
+        const int l = g.len[c];
+        uint32_t col[256];
+        load_column(g, c, l, col);
         int w = 0; unsigned prev = 0;
         for (int k = 0; k < l; k++) {
-            const uint32_t r = col_rec(g, c, k, l);
+            const uint32_t r = col[k];
             if (!rec_hole(r) && w < L) {
                 const size_t o = s * (size_t)L + w;
                 omat[o] = (uint8_t)rec_mat(r); ozp[2 * o] = (uint16_t)prev; ozp[2 * o + 1] = (uint16_t)rec_z1(r);
@@ -1173,17 +1227,22 @@ __global__ __launch_bounds__(256) void k_scatter_columns(GridView g, size_t col0
 // ------------------------------------------------------------------------------------------
 // the two forms of a column
 // ------------------------------------------------------------------------------------------
-// split -> whole: the top interval takes its place in the planes
+// split -> whole: the chain top -> link -> prv -> ... is laid out by index in the planes.  A
+// column's planes are its own, so it is read completely before anything of it is written.
 __global__ __launch_bounds__(256) void k_demote(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
-        if (l > 0) g.rec[(size_t)(l - 1) * g.N + c] = g.top[c];
+        if (l == 0) continue;
+        uint32_t col[256];
+        load_column(g, c, l, col);
+        for (int k = 0; k < l; k++) g.rec[(size_t)k * g.N + c] = col[k];
     }
 }
 
-// whole -> split: top / topz0 from the planes, and the RUN flag of every interval brought up to
-// date (the kernels that restructure columns do not maintain it)
+// whole -> split: top / topz0 / link from the planes (interval k stays in plane k, chained to
+// plane k-1), and the RUN flag of every interval brought up to date (the kernels that
+// restructure columns do not maintain it)
 __global__ __launch_bounds__(256) void k_promote(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
@@ -1192,6 +1251,7 @@ __global__ __launch_bounds__(256) void k_promote(GridView g) {
         for (int k = 0; k < l; k++) {
             r = g.rec[(size_t)k * g.N + c];
             z0 = prev; prev = rec_z1(r);
+            if (k > 0 && k < l - 1) g.prv[(size_t)k * g.N + c] = (uint8_t)(k - 1);
             if (rec_hole(r)) continue;
             const uint32_t want = (r & ~REC_RUN) | ((below_mat == rec_mat(r)) ? REC_RUN : 0u);
             if (want != r) { r = want; g.rec[(size_t)k * g.N + c] = r; }
@@ -1199,6 +1259,7 @@ __global__ __launch_bounds__(256) void k_promote(GridView g) {
         }
         g.top[c] = l > 0 ? r : 0;
         g.topz0[c] = (uint16_t)(l > 0 ? z0 : 0);
+        g.link[c] = (uint8_t)(l > 1 ? l - 2 : 0);
     }
 }
 

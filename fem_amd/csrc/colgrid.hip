@@ -25,7 +25,7 @@ static int vu_setting() {
     return v;
 }
 template <bool ETCH>
-static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t);
+static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, int P);
 // columns per tile row of the symmetric stencil kernel (tuning knob: env CG_TJS = 64, 128, 256)
 static int sym_tile_cols() {
     static int v = [] { const char* e = getenv("CG_TJS"); int x = e ? atoi(e) : 64; return (x == 64 || x == 128 || x == 256) ? x : 64; }();
@@ -55,6 +55,7 @@ struct ConfKernel {
 
 struct Snapshot {
     uint8_t* len = nullptr; uint32_t* rec = nullptr; uint32_t* top = nullptr; uint16_t* topz0 = nullptr;
+    uint8_t* link = nullptr; uint8_t* prv = nullptr; int nextp = 0;
     bool split = true;
     int lmax = 0; int len_bound = 0; bool has_gaps = false, has_cavity = false;
 };
@@ -78,6 +79,8 @@ struct cg_grid {
     uint8_t* len = nullptr; uint32_t* rec = nullptr;      // see cg_kernels.hip.h for the layout
     uint32_t* top = nullptr; uint16_t* topz0 = nullptr;   // split form: top interval of every column and its bottom
     uint32_t* top_alt = nullptr;                          // the buffer a lateral step writes its new tops to (then swapped)
+    uint8_t* link = nullptr; uint8_t* prv = nullptr;      // split form: chain of a column's intervals through the planes
+    int nextp = 0;                                        // split form: first plane no interval lives in yet
     bool split = true;                                    // which form the columns are in right now
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<uint8_t*> masks;
@@ -168,6 +171,7 @@ int js_to_int32(double v) {                  // (v | 0)
 GridView view(const cg_grid* g) {
     GridView v;
     v.len = g->len; v.rec = g->rec; v.top = g->top; v.top_w = g->top; v.topz0 = g->topz0; v.split = g->split ? 1 : 0;
+    v.link = g->link; v.prv = g->prv; v.P = -1;
     v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
     return v;
 }
@@ -183,7 +187,9 @@ void free_planes(cg_grid* g) {
     if (g->top) (void)hipFree(g->top);
     if (g->topz0) (void)hipFree(g->topz0);
     if (g->top_alt) (void)hipFree(g->top_alt);
-    g->len = nullptr; g->rec = nullptr; g->top = nullptr; g->topz0 = nullptr; g->top_alt = nullptr;
+    if (g->link) (void)hipFree(g->link);
+    if (g->prv) (void)hipFree(g->prv);
+    g->len = nullptr; g->rec = nullptr; g->top = nullptr; g->topz0 = nullptr; g->top_alt = nullptr; g->link = nullptr; g->prv = nullptr;
 }
 
 int alloc_planes(cg_grid* g, int lmax) {
@@ -194,6 +200,8 @@ int alloc_planes(cg_grid* g, int lmax) {
     HIPCHK(g, hipMalloc(&g->top, std::max<size_t>(4 * g->N, 16)));
     HIPCHK(g, hipMalloc(&g->topz0, std::max<size_t>(2 * g->N, 16)));
     HIPCHK(g, hipMalloc(&g->top_alt, std::max<size_t>(4 * g->N, 16)));
+    HIPCHK(g, hipMalloc(&g->link, std::max<size_t>(g->N, 16)));
+    HIPCHK(g, hipMalloc(&g->prv, std::max<size_t>(S, 16)));
     g->lmax = lmax;
     return CG_OK;
 }
@@ -206,19 +214,22 @@ int zero_planes(cg_grid* g, bool all = true) {
     HIPCHK(g, hipMemsetAsync(g->len, 0, g->N, g->stream));
     HIPCHK(g, hipMemsetAsync(g->top, 0, 4 * g->N, g->stream));
     HIPCHK(g, hipMemsetAsync(g->topz0, 0, 2 * g->N, g->stream));
-    g->split = true;
+    g->split = true; g->nextp = 0;
     g->len_bound = 0; g->has_gaps = false; g->has_cavity = false;
     return CG_OK;
 }
 
 // The kernels of the vertical and lateral steps work on the split form, the ones that
 // restructure whole columns (strip, cavity, CMP, wet etch, ALD, upload) on whole stacks.
+int refresh_len_bound(cg_grid* g, unsigned* topq_out);
 int ensure_split(cg_grid* g) {
     if (g->split) return CG_OK;
+    if (g->len_bound > g->lmax) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; }
     ProfScope ps(g, CG_K_OTHER);
     hipLaunchKernelGGL(k_promote, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g));
     HIPCHK(g, hipGetLastError());
     g->split = true;
+    g->nextp = std::max(0, g->len_bound - 1);              // interval k lives in plane k: planes 0 .. max(len)-2 are taken
     return CG_OK;
 }
 int ensure_whole(cg_grid* g) {
@@ -242,7 +253,13 @@ int grow_planes(cg_grid* g, int add = 16) {
     HIPCHK(g, hipMemsetAsync(nr + So, 0, 4 * (Sn - So), g->stream));
     HIPCHK(g, hipStreamSynchronize(g->stream));
     (void)hipFree(g->rec);
-    g->rec = nr; g->lmax = newL;
+    g->rec = nr;
+    uint8_t* np = nullptr;
+    HIPCHK(g, hipMalloc(&np, Sn));
+    HIPCHK(g, hipMemcpyAsync(np, g->prv, So, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipStreamSynchronize(g->stream));
+    (void)hipFree(g->prv);
+    g->prv = np; g->lmax = newL;
     return CG_OK;
 }
 
@@ -386,18 +403,35 @@ int ensure_stencil_scratch(cg_grid* g, int R, bool need_halo) {
     return CG_OK;
 }
 
+// The plane a depositing launch pushes old tops into: every such launch gets a fresh one, so
+// its writes are dense whatever the column lengths.  When the planes run out the columns are
+// compacted (whole form and back: interval k in plane k), which frees every plane above max(len)-2.
+int take_append_plane(cg_grid* g, int* P) {
+    if (g->nextp >= g->lmax) {
+        int rc = ensure_whole(g); if (rc) return rc;
+        rc = refresh_len_bound(g, nullptr); if (rc) return rc;
+        rc = ensure_split(g); if (rc) return rc;
+        if (g->nextp >= g->lmax) { rc = grow_planes(g); if (rc) return rc; }
+    }
+    *P = g->nextp++;
+    return CG_OK;
+}
+
 // vertical deposit with the plane-overflow protocol (see k_depo_vertical)
 int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
+    int P = 0;
+    { int rcp = take_append_plane(g, &P); if (rcp) return rcp; }
     bool may_overflow = g->len_bound >= g->lmax;
     if (may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; may_overflow = g->len_bound >= g->lmax; }
     if (may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
     const dim3 grid(blocks_for(g->N)), blk(256);
     ProfScope ps(g, CG_K_DEPO_VERTICAL);
+    GridView gv = view(g); gv.P = P;
     if (g->N % 4 == 0) {        // 4 columns per thread
-        launch_vertical<false>(g, mask, mat, t);
+        launch_vertical<false>(g, mask, mat, t, P);
     } else {
-        if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<false, true>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
-        else hipLaunchKernelGGL((k_vertical_1<false, false>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
+        if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<false, true>), grid, blk, 0, g->stream, gv, mask, mat, t, -1, g->d_flags, g->d_stats);
+        else hipLaunchKernelGGL((k_vertical_1<false, false>), grid, blk, 0, g->stream, gv, mask, mat, t, -1, g->d_flags, g->d_stats);
     }
     HIPCHK(g, hipGetLastError());
     if (may_overflow) {
@@ -405,8 +439,9 @@ int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
         if (fl[0]) {
             const int oldL = g->lmax;
             rc = grow_planes(g); if (rc) return rc;
-            if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<false, true>), grid, blk, 0, g->stream, view(g), mask, mat, t, oldL, g->d_flags, g->d_stats);
-            else hipLaunchKernelGGL((k_vertical_1<false, false>), grid, blk, 0, g->stream, view(g), mask, mat, t, oldL, g->d_flags, g->d_stats);
+            gv = view(g); gv.P = P;
+            if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<false, true>), grid, blk, 0, g->stream, gv, mask, mat, t, oldL, g->d_flags, g->d_stats);
+            else hipLaunchKernelGGL((k_vertical_1<false, false>), grid, blk, 0, g->stream, gv, mask, mat, t, oldL, g->d_flags, g->d_stats);
             HIPCHK(g, hipGetLastError());
         }
     }
@@ -416,9 +451,9 @@ int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
 
 // New tops go to top_alt (the caller swaps the buffers when the step is complete).
 int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t_eff, int R, ConfKernel* K, int only_len,
-                   const uint8_t* halo_lo, const uint8_t* halo_up) {
+                   const uint8_t* halo_lo, const uint8_t* halo_up, int P) {
     GridView gv = view(g);
-    gv.top_w = g->top_alt;
+    gv.top_w = g->top_alt; gv.P = P;
     const int tiles = ((g->nx + TI - 1) / TI) * ((g->ny + TJ - 1) / TJ);
     const size_t lds = stencil_lds_bytes(R);
     const dim3 grid(tiles), blk(256);
@@ -608,14 +643,15 @@ int ald_coat(cg_grid* g, int mat, double t) {
 }  // namespace
 
 template <bool ETCH>
-static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
+static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, int P) {
+    GridView gv = view(g); gv.P = P;
     const int U = getenv("CG_VU") ? vu_setting() : 1;
     // one tile per workgroup: measured 25 % faster than a capped, sweeping grid for this access mix
     static const long cap = [] { const char* e = getenv("CG_VGRID"); return e ? atol(e) : 0L; }();
     size_t nb = (g->N / 4 + (size_t)256 * U - 1) / ((size_t)256 * U);
     if (cap > 0) nb = std::min<size_t>(nb, (size_t)cap);
     const dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>(nb, 0x7fffffff))), blk(256);
-#define LV(S, UU) hipLaunchKernelGGL((k_vertical_g4<ETCH, S, UU>), grid, blk, 0, g->stream, view(g), mask, mat, t, g->d_flags, g->d_stats)
+#define LV(S, UU) hipLaunchKernelGGL((k_vertical_g4<ETCH, S, UU>), grid, blk, 0, g->stream, gv, mask, mat, t, g->d_flags, g->d_stats)
     if (g->stats_on) { if (U == 1) LV(true, 1); else if (U == 2) LV(true, 2); else LV(true, 4); }
     else { if (U == 1) LV(false, 1); else if (U == 2) LV(false, 2); else LV(false, 4); }
 #undef LV
@@ -680,7 +716,7 @@ int cg_destroy(cg_grid* g) {
     free_planes(g);
     for (auto m : g->masks) if (m) (void)hipFree(m);
     for (auto k : g->kcache) free_kernel(k);
-    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.rec); (void)hipFree(s.second.top); (void)hipFree(s.second.topz0); }
+    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.rec); (void)hipFree(s.second.top); (void)hipFree(s.second.topz0); (void)hipFree(s.second.link); (void)hipFree(s.second.prv); }
     if (!g->halo_external) for (auto h : g->halo) if (h) (void)hipFree(h);
     for (auto& r : g->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
@@ -825,7 +861,7 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
         const dim3 grid(blocks_for(g->N)), blk(256);
         ProfScope ps(g, CG_K_ETCH_VERTICAL);
         if (g->N % 4 == 0) {    // 4 columns per thread
-            launch_vertical<true>(g, mask, mat, t);
+            launch_vertical<true>(g, mask, mat, t, -1);
         } else if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<true, true>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
         else hipLaunchKernelGGL((k_vertical_1<true, false>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
         HIPCHK(g, hipGetLastError());
@@ -892,7 +928,7 @@ int cg_stencil_finish(cg_grid* g) {
     const uint8_t* halo_lo = p.has_lower ? g->halo[2] : nullptr;
     const uint8_t* halo_up = p.has_upper ? g->halo[3] : nullptr;
     if (etch) {
-        int rc = launch_stencil(g, true, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up); if (rc) return rc;
+        int rc = launch_stencil(g, true, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, -1); if (rc) return rc;
         std::swap(g->top, g->top_alt);
         return CG_OK;
     }
@@ -900,13 +936,15 @@ int cg_stencil_finish(cg_grid* g) {
     bool may_overflow = g->len_bound >= g->lmax;
     if (may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; may_overflow = g->len_bound >= g->lmax; }
     if (may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
-    int rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up); if (rc) return rc;
+    int P = 0;
+    int rc = take_append_plane(g, &P); if (rc) return rc;
+    rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, P); if (rc) return rc;
     if (may_overflow) {
         int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
         if (fl[0]) {
             const int oldL = g->lmax;
             rc = grow_planes(g); if (rc) return rc;
-            rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, oldL, halo_lo, halo_up); if (rc) return rc;
+            rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, oldL, halo_lo, halo_up, P); if (rc) return rc;
         }
     }
     std::swap(g->top, g->top_alt);
@@ -1369,6 +1407,10 @@ int cg_snapshot_save(cg_grid* g, int slot) {
     Snapshot s; size_t S = g->N * (size_t)g->lmax;
     HIPCHK(g, hipMalloc(&s.len, std::max<size_t>(g->N, 4))); HIPCHK(g, hipMalloc(&s.rec, std::max<size_t>(4 * S, 4)));
     HIPCHK(g, hipMalloc(&s.top, std::max<size_t>(4 * g->N, 16))); HIPCHK(g, hipMalloc(&s.topz0, std::max<size_t>(2 * g->N, 16)));
+    HIPCHK(g, hipMalloc(&s.link, std::max<size_t>(g->N, 16))); HIPCHK(g, hipMalloc(&s.prv, std::max<size_t>(S, 16)));
+    HIPCHK(g, hipMemcpyAsync(s.link, g->link, g->N, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(s.prv, g->prv, S, hipMemcpyDeviceToDevice, g->stream));
+    s.nextp = g->nextp;
     HIPCHK(g, hipMemcpyAsync(s.len, g->len, g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(s.rec, g->rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(s.top, g->top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
@@ -1391,6 +1433,9 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     HIPCHK(g, hipMemcpyAsync(g->rec, s.rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->top, s.top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->topz0, s.topz0, 2 * g->N, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(g->link, s.link, g->N, hipMemcpyDeviceToDevice, g->stream));
+    HIPCHK(g, hipMemcpyAsync(g->prv, s.prv, S, hipMemcpyDeviceToDevice, g->stream));
+    g->nextp = s.nextp;
     g->split = s.split;
     g->len_bound = s.len_bound; g->has_gaps = s.has_gaps; g->has_cavity = s.has_cavity;
     return CG_OK;
@@ -1402,6 +1447,7 @@ int cg_snapshot_drop(cg_grid* g, int slot) {
     if (it == g->snaps.end()) return CG_OK;
     HIPCHK(g, hipStreamSynchronize(g->stream));
     (void)hipFree(it->second.len); (void)hipFree(it->second.rec); (void)hipFree(it->second.top); (void)hipFree(it->second.topz0);
+    (void)hipFree(it->second.link); (void)hipFree(it->second.prv);
     g->snaps.erase(it);
     return CG_OK;
 }
