@@ -300,8 +300,10 @@ __device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsign
         const size_t b = (size_t)g.P * g.N + c0;
         u16x4 z; u8x4 nk = lk;
         if (app == 15u) {
-            st_rec4(g.rec + b, tv);
-            st_u8x4(g.prv + b, lk);
+            if (as_u32(ln) != 0u) {                            // (columns that were empty push nothing)
+                st_rec4(g.rec + b, tv);
+                st_u8x4(g.prv + b, lk);
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) { z[j] = (unsigned short)rec_z1(ln[j] ? tv[j] : 0); if (ln[j]) nk[j] = (uint8_t)g.P; }
         } else {
