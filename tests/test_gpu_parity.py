@@ -334,6 +334,39 @@ def test_same_material_runs_across_gaps_and_form_changes():
     g.close()
 
 
+def test_many_deposit_steps_recycle_planes():
+    """Every depositing launch takes a plane of its own; with 32 planes and 90 deposits on short
+    columns the engine has to compact the columns several times.  Oracle equality after every step,
+    snapshots across a compaction included."""
+    fem = _engine()
+    nx, ny = 72, 64
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    rng = _lcg(9)
+    masks = []
+    for _ in range(3):
+        red = fem.reduce_mask(_random_mask_data(rng, 2 * nx, 9))
+        masks.append((g.mask_from_shapes(red), o.mask_raster(red)))
+    saved = None
+    for k in range(90):
+        gm, om = masks[k % 3] if k % 4 else (None, None)
+        mat = 3 + k % 4
+        S = [0, 0, 1.0, 0.5][k % 4]
+        g.deposit_general(gm, mat, 1.5 + (k % 5), S); o.deposit_general(om, mat, 1.5 + (k % 5), S)
+        assert g.checksum() == o.checksum(), f"deposit {k}"
+        gm, om = masks[(k + 1) % 3]
+        g.etch_general(gm, 255, 2.0 + (k % 7), [0, 1.0, 0][k % 3]); o.etch_general(om, 255, 2.0 + (k % 7), [0, 1.0, 0][k % 3])
+        assert g.checksum() == o.checksum(), f"etch {k}"
+        if k == 20:
+            g.snapshot_save(7); saved = o.arrays() + (o.Lmax,)
+        if k == 60:                                   # back to the state of step 20, then on
+            g.snapshot_load(7); o.upload(*saved)
+            assert g.checksum() == o.checksum()
+    assert g.Lmax == o.Lmax == 32
+    _assert_same(g, o.arrays(), "final")
+    g.close()
+
+
 def test_upload_download_roundtrip_and_slices():
     fem = _engine()
     case = load_case("stencil_small")
