@@ -16,12 +16,13 @@ keep = lambda n: ("cgk::" in n) and not any(x in n for x in ("mask", "checksum",
 fe = [r for r in rows("pmc_fetch/**/*counter_collection.csv") if keep(r["Kernel_Name"])]
 wr = [r for r in rows("pmc_write/**/*counter_collection.csv") if keep(r["Kernel_Name"])]
 tr = [r for r in rows("trace/**/*kernel_trace.csv") if keep(r["Kernel_Name"])]
-print("dispatches", len(fe), len(wr), len(tr))
+print("dispatches", len(fe), len(wr), len(tr), "| fetch = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB (separate rocprofv3 --pmc passes), time from --kernel-trace")
 n = min(len(fe), len(wr), len(tr))
 half = n // 2          # step_times.py runs the flow twice; print the second (untimed-stats-free) pass
 for k in range(half, n):
     name = fe[k]["Kernel_Name"].split("(")[0].replace("void cgk::", "")[:44]
-    f = float(fe[k]["Counter_Value"]) / 1e6; w = float(wr[k]["Counter_Value"]) / 1e6
+    # counters are KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B)
+    f = 2 * float(fe[k]["Counter_Value"]) * 1024 / 1e9; w = float(wr[k]["Counter_Value"]) * 1024 / 1e9
     ms = (int(tr[k]["End_Timestamp"]) - int(tr[k]["Start_Timestamp"])) / 1e6
     print("%3d %-44s fetch %7.3f GB  write %7.3f GB  %7.3f ms  (f+w)/t %7.1f GB/s" % (k - half, name, f, w, ms, (f + w) / ms * 1e3 if ms else 0))
 PY
