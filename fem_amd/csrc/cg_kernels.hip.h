@@ -652,7 +652,9 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
 // outside the ellipse, and entries that need double evaluation, hold -infinity so that they
 // never win.  max(h1,h2,h3,h4)+a == max(h1+a,...,h4+a) exactly because rounding is monotone:
 // one add and one max serve four taps.
-template <int R> struct AddTab { float a[(R + 1) * (R + 1)]; };
+// lim[du] = largest dv whose entry of row du is a float32 tap (-1: none); the ellipse is convex, so
+// the entries 0..lim[du] of a row are the valid ones and the loops stop there (uniform branches).
+template <int R> struct AddTab { float a[(R + 1) * (R + 1)]; int lim[R + 1]; };
 
 // Tile of the symmetric kernel: TJS columns x (1024 / TJS) rows per block of 256 threads.
 template <int R, int TJS> struct SymGeom {
@@ -746,13 +748,19 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                 // for etch, own of a non-etchable column is +inf; it is never used (act bit clear)
                 m[c] = ETCH ? (float)((double)own[c] - t) : (float)((double)own[c] + t);     // cg1:702 / cg1:499
             }
-#define CG_OP(a, b) (ETCH ? fminf((a), (b)) : fmaxf((a), (b)))
+// Deposit: max of non-negative floats (and -inf) is the max of their bit patterns as signed
+// integers.  Etch: the candidates are >= 0, +inf, or negative; every negative result is clamped
+// to 0 afterwards (cg1:725), so it only has to compare below the non-negative ones -- which a
+// negative float does as a signed integer too.  No NaN can occur, and the integer form needs
+// no canonicalisation of loaded values (and fuses into v_max3/v_min3).
+#define CG_OP(a, b) __int_as_float(ETCH ? min(__float_as_int(a), __float_as_int(b)) : max(__float_as_int(a), __float_as_int(b)))
 #define CG_ADD(x, a) (ETCH ? ((x) - (a)) : ((x) + (a)))
             // centre row
 #pragma unroll
             for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(hc[Rp + c], tab.a[0]));
 #pragma unroll
             for (int dv = 1; dv <= R; dv++) {
+                if (dv > tab.lim[0]) break;
                 const float a = tab.a[dv];
 #pragma unroll
                 for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(CG_OP(hc[Rp + c + dv], hc[Rp + c - dv]), a));
@@ -760,6 +768,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
             // row pairs +-du: v[k] = op(row+du[k], row-du[k]) is shared by every dv
 #pragma unroll
             for (int du = 1; du <= R; du++) {
+                if (tab.lim[du] < 0) continue;
                 float v[W];
 #pragma unroll
                 for (int k = 0; k < W / 4; k++) {
@@ -772,6 +781,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                 for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(v[Rp + c], a0));
 #pragma unroll
                 for (int dv = 1; dv <= R; dv++) {
+                    if (dv > tab.lim[du]) break;
                     const float a = tab.a[du * (R + 1) + dv];
 #pragma unroll
                     for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(CG_OP(v[Rp + c + dv], v[Rp + c - dv]), a));

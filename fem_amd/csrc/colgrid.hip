@@ -463,6 +463,10 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
 #define SYM(RR, TT, E, S)                                                                                      \
     do {                                                                                                       \
         AddTab<RR> tab; memcpy(tab.a, K->quad.data(), sizeof tab.a);                                           \
+        for (int du_ = 0; du_ <= RR; du_++) {                                                                  \
+            tab.lim[du_] = -1;                                                                                 \
+            for (int dv_ = 0; dv_ <= RR; dv_++) if (tab.a[du_ * (RR + 1) + dv_] != -INFINITY) tab.lim[du_] = dv_; \
+        }                                                                                                      \
         const int tis = 1024 / TT;                                                                             \
         const dim3 gridS(((g->nx + tis - 1) / tis) * ((g->ny + TT - 1) / TT));                                 \
         hipLaunchKernelGGL((k_stencil_sym<RR, TT, E, S>), gridS, blk, 0, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
