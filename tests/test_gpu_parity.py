@@ -367,6 +367,66 @@ def test_many_deposit_steps_recycle_planes():
     g.close()
 
 
+@pytest.mark.parametrize("dx,zs,lmax", [(1.0, 0.1, 32), (2.0, 0.05, 32), (3.0, 0.25, 16), (0.5, 0.2, 32), (2.0, 0.1, 4), (2.0, 0.1, 1)])
+def test_other_pitches_and_height_steps(dx, zs, lmax):
+    """Cell pitch and height quantum other than the defaults (2 nm, 0.1 nm), small initial Lmax
+    (1 -> 2: script_columngrid.js:302-304): every step kind against the oracle."""
+    fem = _engine()
+    nx, ny = 64, 48
+    g = fem.ColumnGrid(dx * nx, dx * ny, dx, dx, lmax, zs)
+    o = OracleGrid(dx * nx, dx * ny, dx, dx, lmax, zs)
+    assert (g.NX, g.NY, g.Lmax) == (o.NX, o.NY, o.Lmax)
+    rng = _lcg(int(dx * 10 + zs * 100))
+    red = fem.reduce_mask(_random_mask_data(rng, int(dx * nx), 7))
+    gm, om = g.mask_from_shapes(red), o.mask_raster(red)
+    np.testing.assert_array_equal(gm.download(), om)
+    t0 = 4 * dx
+    steps = [("d", None, 3, 5 * t0, 0), ("d", None, 4, 1.3 * t0, 0), ("d", gm, 5, 2.1 * t0, 0), ("e", gm, 255, 3.3 * t0, 0),
+             ("d", None, 6, 1.7 * t0, 1.0), ("e", None, 6, 0.9 * t0, 1.0), ("s", None, 4), ("d", None, 7, t0, 0.7),
+             ("p", None, 0, 0.8 * t0), ("e", gm, 3, 1.2 * t0, 0.5), ("c",)]
+    for idx, st in enumerate(steps):
+        kind = st[0]
+        for grid, m in ((g, gm), (o, om)):
+            mask = m if (len(st) > 1 and st[1] is not None) else None
+            if kind == "d":
+                grid.deposit_general(mask, st[2], st[3], st[4])
+            elif kind == "e":
+                grid.etch_general(mask, st[2], st[3], st[4])
+            elif kind == "s":
+                grid.strip_connected(st[2])
+            elif kind == "p":
+                grid.cmp(st[3], st[2])
+            else:
+                grid.identify_cavity()
+        if o.arrays()[0].max() >= o.Lmax and kind in ("d", "p", "c"):
+            break      # a column fills every slot at a cavity pass: the reference corrupts its arrays there (no bound check, cg2:60-69)
+        assert g.checksum() == o.checksum(), f"step {idx} {st}"
+        assert g.Lmax == o.Lmax and g.maxHeight() == o.max_height(), f"step {idx}"
+    else:
+        _assert_same(g, o.arrays(), "final")
+    g.close()
+
+
+def test_unequal_pitch_vertical_only():
+    """dx != dy: vertical steps match the oracle; lateral steps are refused (the reference pads its
+    height map with Rx in both directions there, script_columngrid.js:471, 666)."""
+    fem = _engine()
+    g = fem.ColumnGrid(120, 90, 2.0, 3.0)
+    o = OracleGrid(120, 90, 2.0, 3.0)
+    assert (g.NX, g.NY) == (o.NX, o.NY) == (60, 30)
+    for mat, t in ((3, 10), (4, 6.5), (3, 2)):
+        g.deposit_general(None, mat, t, 0); o.deposit_general(None, mat, t, 0)
+    g.etch_general(None, 255, 4.4, 0); o.etch_general(None, 255, 4.4, 0)
+    g.deposit_general(None, 5, 1.9, 1.0); o.deposit_general(None, 5, 1.9, 1.0)     # t*S < min(dx, dy): still vertical
+    assert g.checksum() == o.checksum()
+    with pytest.raises(fem.ColGridError):
+        g.deposit_general(None, 5, 8, 1.0)
+    with pytest.raises(fem.ColGridError):
+        g.etch_general(None, 5, 8, 1.0)
+    assert g.checksum() == o.checksum()
+    g.close()
+
+
 def test_upload_download_roundtrip_and_slices():
     fem = _engine()
     case = load_case("stencil_small")
