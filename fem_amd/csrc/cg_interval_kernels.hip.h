@@ -295,6 +295,7 @@ __global__ void k_ald_air(GridView g, AldLayout L, uint16_t* __restrict__ air_n,
     extern __shared__ uint32_t lds[];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const BitCol b{lds + threadIdx.x, (int)blockDim.x, L.wpc};
+    int nmax = 0;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         b.clear();
         mark_occupied(g, c, b);
@@ -305,7 +306,11 @@ __global__ void k_ald_air(GridView g, AldLayout L, uint16_t* __restrict__ air_n,
             if (FILL && n < planes) air[(size_t)n * g.N + c] = make_uint2((unsigned)s, (unsigned)e);
             n++;
         });
-        if (!FILL) { air_n[c] = (uint16_t)min(n, 65535); if (n > flags[3]) atomicMax(&flags[3], n); }
+        if (!FILL) { air_n[c] = (uint16_t)min(n, 65535); nmax = max(nmax, n); }
+    }
+    if (!FILL) {
+        for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_down(nmax, o, 64));
+        if ((threadIdx.x & 63) == 0 && nmax > 0) atomicMax(&flags[3], nmax);
     }
 }
 
@@ -322,6 +327,8 @@ __global__ __launch_bounds__(256) void k_ald_seeds(GridView g, unsigned H0q, con
                                                    uint16_t* __restrict__ seed_n, uint2* __restrict__ seed, int planes, int* __restrict__ bbox,
                                                    int* __restrict__ flags, unsigned long long* __restrict__ total) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    int imin = 0x7fffffff, imax = -1, jmin = 0x7fffffff, jmax = -1, nmax = 0;      // reduced per wave before the atomics
+    unsigned long long nsum = 0;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
         const int i = (int)(c / g.ny), j = (int)(c - (size_t)i * g.ny);
@@ -354,10 +361,21 @@ __global__ __launch_bounds__(256) void k_ald_seeds(GridView g, unsigned H0q, con
                 }
             }
         }
-        if (!FILL) { seed_n[c] = (uint16_t)min(n, 65535); if (n > flags[3]) atomicMax(&flags[3], n); if (n) atomicAdd(total, (unsigned long long)n); }
-        else if (n > 0) { atomicMin(&bbox[0], i); atomicMax(&bbox[1], i); atomicMin(&bbox[2], j); atomicMax(&bbox[3], j); }
+        if (!FILL) { seed_n[c] = (uint16_t)min(n, 65535); nmax = max(nmax, n); nsum += (unsigned long long)n; }
+        else if (n > 0) { imin = min(imin, i); imax = max(imax, i); jmin = min(jmin, j); jmax = max(jmax, j); }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        imin = min(imin, __shfl_down(imin, o, 64)); imax = max(imax, __shfl_down(imax, o, 64));
+        jmin = min(jmin, __shfl_down(jmin, o, 64)); jmax = max(jmax, __shfl_down(jmax, o, 64));
+        nmax = max(nmax, __shfl_down(nmax, o, 64)); nsum += __shfl_down(nsum, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (!FILL) { if (nmax > 0) atomicMax(&flags[3], nmax); if (nsum) atomicAdd(total, nsum); }
+        else if (imax >= 0) { atomicMin(&bbox[0], imin); atomicMax(&bbox[1], imax); atomicMin(&bbox[2], jmin); atomicMax(&bbox[3], jmax); }
     }
 }
+
+
 
 // --- inserting a bitset's runs into a column (applyCoatFromBits, cg2:585-682) ---------------
 struct AldOut {                                                // the adjacency pass, cg2:634-655

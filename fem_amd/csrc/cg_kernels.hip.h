@@ -1058,30 +1058,37 @@ __device__ __forceinline__ bool layer_exposed(const GridView& g, const Ghost& gh
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh, int matId) {
+// cand[c] = 1 while column c still has an unmarked node of matId: the sweeps skip the others
+// after reading one byte.
+__global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
-        if (l == 0) continue;
+        if (l == 0) { cand[c] = 0; continue; }
+        bool open_node = false;
         const int i = (int)(c / g.ny), j = (int)(c - (size_t)i * g.ny);
         const unsigned topq = rec_z1(g.rec[(size_t)(l - 1) * g.N + c]);
         unsigned prev = 0;
         for (int k = 0; k < l; k++) {
             const uint32_t r = g.rec[(size_t)k * g.N + c];
-            if (!rec_hole(r) && rec_mat(r) == matId && layer_exposed(g, gh, i, j, prev, rec_z1(r), topq))
-                g.rec[(size_t)k * g.N + c] = r | REC_MARK;
+            if (!rec_hole(r) && rec_mat(r) == matId) {
+                if (layer_exposed(g, gh, i, j, prev, rec_z1(r), topq)) g.rec[(size_t)k * g.N + c] = r | REC_MARK;
+                else open_node = true;
+            }
             prev = rec_z1(r);
         }
+        cand[c] = open_node ? 1 : 0;
     }
 }
 
 // one relaxation sweep: an unmarked node next to an overlapping marked node becomes marked
-__global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int matId, int* __restrict__ changed) {
+__global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand, int* __restrict__ changed) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     int any = 0;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        if (!cand[c]) continue;
         const int l = g.len[c];
-        if (l == 0) continue;
+        bool open_node = false;
         const int i = (int)(c / g.ny), j = (int)(c - (size_t)i * g.ny);
         unsigned prev = 0;
         for (int k = 0; k < l; k++) {
@@ -1105,7 +1112,9 @@ __global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int m
                 }
             }
             if (hit) { g.rec[(size_t)k * g.N + c] = r | REC_MARK; any = 1; }
+            else open_node = true;
         }
+        if (!open_node) cand[c] = 0;
     }
     if (any) *changed = 1;
 }

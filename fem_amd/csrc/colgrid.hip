@@ -113,6 +113,7 @@ struct cg_grid {
     uint16_t* seed_n = nullptr; uint2* seed = nullptr; int seed_planes = 0; bool has_seeds = false;
     int seed_bbox[4] = {0, -1, 0, -1}; uint64_t seed_total = 0;
     int* d_bbox = nullptr;
+    uint8_t* cand = nullptr;                               // strip_connected: columns that still hold an unmarked node
     AldTap* d_ald_taps = nullptr; int ald_taps_cap = 0;
     std::string err;
 };
@@ -728,6 +729,7 @@ int cg_destroy(cg_grid* g) {
     if (g->d_red) (void)hipFree(g->d_red);
     if (g->d_sum) (void)hipFree(g->d_sum);
     if (g->d_bbox) (void)hipFree(g->d_bbox);
+    if (g->cand) (void)hipFree(g->cand);
     if (g->d_ald_taps) (void)hipFree(g->d_ald_taps);
     free_alt(g, 0); free_alt(g, 1); drop_seeds(g);
     if (g->d_stats) (void)hipFree(g->d_stats);
@@ -1053,8 +1055,9 @@ int cg_strip_seed(cg_grid* g, int mat, int planes, const void* ghost_lower, cons
     if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
     g->pend.active = false;
     int rc = ensure_whole(g); if (rc) return rc;
+    if (!g->cand) HIPCHK(g, hipMalloc(&g->cand, std::max<size_t>(g->N, 16)));
     ProfScope ps(g, CG_K_OTHER);
-    hipLaunchKernelGGL(k_strip_seed, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), make_ghost(g, planes, ghost_lower, ghost_upper), mat);
+    hipLaunchKernelGGL(k_strip_seed, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), make_ghost(g, planes, ghost_lower, ghost_upper), mat, g->cand);
     HIPCHK(g, hipGetLastError());
     return CG_OK;
 }
@@ -1062,7 +1065,7 @@ int cg_strip_seed(cg_grid* g, int mat, int planes, const void* ghost_lower, cons
 int cg_strip_sweep(cg_grid* g, int mat, int planes, const void* ghost_lower, const void* ghost_upper, int* changed) {
     NEED(g);
     if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
-    if (g->split) return fail(g, CG_ERR_STATE, "cg_strip_sweep without cg_strip_seed");
+    if (g->split || !g->cand) return fail(g, CG_ERR_STATE, "cg_strip_sweep without cg_strip_seed");
     ProfScope ps(g, CG_K_OTHER);
     const dim3 grid(blocks_for(g->N)), blk(256);
     const Ghost gh = make_ghost(g, planes, ghost_lower, ghost_upper);
@@ -1071,7 +1074,7 @@ int cg_strip_sweep(cg_grid* g, int mat, int planes, const void* ghost_lower, con
     for (int round = 0;; round++) {
         if (round > 1000000) return fail(g, CG_ERR_STATE, "strip_connected did not converge");
         HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
-        for (int sweep = 0; sweep < 4; sweep++) hipLaunchKernelGGL(k_strip_flood, grid, blk, 0, g->stream, view(g), gh, mat, g->d_flags);
+        for (int sweep = 0; sweep < 4; sweep++) hipLaunchKernelGGL(k_strip_flood, grid, blk, 0, g->stream, view(g), gh, mat, g->cand, g->d_flags);
         HIPCHK(g, hipGetLastError());
         int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
         if (!fl[0]) break;
