@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcolgrid.so")
 CG_MASK_NONE = -1
 CG_NSTAT = 8
 CG_NKIND = 12
-KERNEL_KINDS = ["k_vertical_g4<deposit>", "k_vertical_g4<etch>", "k_snapshot_tops_g4", "k_halo_pack/unpack",
+KERNEL_KINDS = ["k_vertical_g4<deposit>", "k_vertical_g4<etch>", "(unused)", "k_halo_pack / k_ghost_pack",
                 "k_stencil_sym<deposit>", "k_stencil_sym<etch>", "k_mask_shapes", "clear(memset)",
                 "k_max_top", "other", "-", "-"]
 STENCIL_DEPOSIT, STENCIL_ETCH = 0, 1

@@ -1,18 +1,33 @@
 // Device code of libcolgrid: the per-column process kernels for gfx950 (MI355X).
 //
-// Data layout (all in HBM, owned by the handle):
-//   len[c]          u8    intervals in column c                   c = i*NY + j, j fastest
-//   rec[k*N + c]    u32   interval k of column c ("plane-major")  z1q | mat << 16 | flags << 24
+// A column is a stack of contiguous intervals z1q | mat << 16 | flags << 24 (u32); interval k
+// spans from the top of interval k-1 (0 for k = 0) to its own z1, so the bottom height is never
+// stored in a record.  That is exactly what the reference's columns look like as long as they
+// have no vertical gaps (every append starts at the old top, script_columngrid.js:419-423).  A
+// gap -- left behind when strip_connected removes a buried layer -- is kept as an interval of
+// its own with the HOLE flag; holes are not layers of the reference (they do not count in its
+// len, cg_download skips them) and the top interval is never a hole.
 //
-// A column is a stack of contiguous intervals; interval k spans from the top of interval k-1
-// (0 for k = 0) to its own z1, so the bottom height is never stored.  That is exactly what the
-// reference's columns look like as long as they have no vertical gaps (every append starts at
-// the old top, script_columngrid.js:419-423).  A gap -- left behind when strip_connected
-// removes a buried layer -- is kept as an interval of its own with the HOLE flag; holes are not
-// layers of the reference (they do not count in its len, cg_download skips them) and the top
-// interval is never a hole.  One 4-byte record per (plane, column) means one memory stream per
-// plane and 16 bytes per 4-column group: HBM is only reached with >= 4 bytes per lane and
-// access (measured on MI355X: 1 B/lane copies at 1.8 TB/s, 2 B/lane 3.0, 4 B/lane 5.4).
+// Two forms of the same columns (all arrays in HBM, owned by the handle; c = i*NY + j, j fastest):
+//
+//   whole form   len[c] u8, rec[k*N + c] = interval k, k < len      (plane-major)
+//                what the kernels that restructure whole columns work on (strip, cavity, CMP,
+//                wet etch, ALD, upload).
+//
+//   split form   len[c] u8, top[c] u32 = the top interval (0: empty column), topz0[c] u16 = its
+//                bottom, link[c] u8 = the plane holding the interval below it, and for an interval
+//                stored in plane p: rec[p*N + c], prv[p*N + c] u8 = the plane of the one below.
+//                What the vertical and lateral steps work on: they only ever look at the top, so
+//                extend / partial etch / "material differs" touch streams whose addresses do not
+//                depend on the column length.  An append pushes the old top into the plane P of
+//                the launch -- every depositing launch takes a fresh plane, so that these writes
+//                fill whole 128-byte lines whatever the lengths of neighbouring columns (measured:
+//                4-byte pieces scattered over planes cost up to 3x, the memory side
+//                read-modify-writes partial lines) -- and the removal of a whole layer follows
+//                link / prv.  Plane slots outside a column's chain hold unspecified data.
+//
+// A thread owns 4 consecutive columns: HBM is only reached with >= 4 bytes per lane and access
+// (measured on MI355X: 1 B/lane copies at 1.8 TB/s, 2 B/lane 3.0, 4 B/lane 5.4, 16 B/lane 5.7).
 //
 // Arithmetic follows the reference's JavaScript: heights are u16 steps of zscale nm,
 // de-quantised as (double)q*zscale, re-quantised as Math.round(z/zscale) (halves toward

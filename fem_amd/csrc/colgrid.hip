@@ -1,6 +1,7 @@
 // libcolgrid: host side of the C ABI declared in include/colgrid.h.
-// Owns the device planes of a grid, the mask rasters, the conformal-kernel cache and the
-// stencil scratch; enqueues the kernels of cg_kernels.hip.h on the handle's stream.
+// Owns the device arrays of a grid (both forms of the columns, see cg_kernels.hip.h), the mask
+// rasters, the conformal-kernel cache and the scratch of the incremental models; enqueues the
+// kernels of cg_kernels.hip.h / cg_interval_kernels.hip.h on the handle's stream.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -3,7 +3,7 @@
 Rank r owns rows i in [r*nx_local, (r+1)*nx_local) of an (nx_local*world) x ny domain.  Columns
 are independent except for the lateral stencil of conformal deposition / isotropic etch, whose
 radius R reaches into the neighbouring slabs.  For those steps each rank
-  1. snapshots its top heights (+ etchable flags)          grid.stencil_begin
+  1. packs the top heights (+ etchable flags) of its R boundary rows   grid.stencil_begin
   2. swaps R boundary rows with its two neighbours          torch.distributed send/recv (RCCL)
   3. runs the dilation / erosion and the column update      grid.stencil_finish
 Layer stacks never move between GPUs.  Whole-domain scalars (max height, checksum, CMP's
