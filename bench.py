@@ -225,7 +225,7 @@ def main():
             "checksum": "%016x" % check,
             "roofline": roofline, "kernels": kernels,
         }
-        if not args.no_cpu and world >= 1:
+        if not args.no_cpu and world == 1:          # the CPU baseline is timed at N=1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(flows, flow, args.cpu_n)
             except Exception as e:  # the baseline is a reported extra, never the measured path
