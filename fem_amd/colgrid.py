@@ -89,6 +89,8 @@ ABI = {
     "cg_ald_increment": (_i, [_vp, _i, _d]),
     "cg_ald_coat": (_i, [_vp, _i, _d]),
     "cg_release_scratch": (_i, [_vp]),
+    "cg_add_layer": (_i, [_vp, _i, _i, _i, _d, _d]),
+    "cg_remove_top_layer": (_i, [_vp, _i, _i]),
     "cg_max_height": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_uint32)]),
     "cg_stencil_begin": (_i, [_vp, _i, _i, _i, _d, _d, _i, _i, C.POINTER(_i)]),
     "cg_halo_buffers": (_i, [_vp, _pp, _pp, _pp, _pp, C.POINTER(_sz)]),
@@ -494,6 +496,14 @@ class ColumnGrid:
         ac = self.sliderCache.get("aldCache"); wc = self.sliderCache.get("wetetchCache")
         return (len(ac["gridWithCavity"]) if ac else 0, len(wc["grid"]) if wc else 0,
                 (ac["exposedSegments"] or 0) if ac else 0)
+
+    def addLayer(self, i, j, matId, z0_real, z1_real):
+        """addLayer (script_columngrid.js:196-211) on one device column."""
+        self._chk(self.lib.cg_add_layer(self.h, int(i), int(j), int(matId) & 255, float(z0_real), float(z1_real)))
+
+    def removeTopLayer(self, i, j):
+        """removeTopLayer (script_columngrid.js:213-218); the freed slot reads back as zeros."""
+        self._chk(self.lib.cg_remove_top_layer(self.h, int(i), int(j)))
 
     def maxHeight(self):
         z = C.c_double()

@@ -935,6 +935,23 @@ __global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restric
     if ((threadIdx.x & 63) == 0) { if (mq) atomicMax(&out[0], mq); if (ml) atomicMax(&out[1], ml); }
 }
 
+// whole form: out[0] = max number of layers (gap intervals not counted), out[1] = max len
+__global__ __launch_bounds__(256) void k_max_layers(GridView g, unsigned* __restrict__ out) {
+    unsigned mw = 0, ml = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const int l = g.len[c];
+        unsigned w = 0;
+        for (int k = 0; k < l; k++) w += rec_hole(g.rec[(size_t)k * g.N + c]) ? 0u : 1u;
+        mw = w > mw ? w : mw; ml = (unsigned)l > ml ? (unsigned)l : ml;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned a = __shfl_down(mw, o, 64), b = __shfl_down(ml, o, 64);
+        mw = a > mw ? a : mw; ml = b > ml ? b : ml;
+    }
+    if ((threadIdx.x & 63) == 0) { if (mw) atomicMax(&out[0], mw); if (ml) atomicMax(&out[1], ml); }
+}
+
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     x += 0x9E3779B97F4A7C15ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -1199,6 +1216,29 @@ __global__ __launch_bounds__(256) void k_cavity_fill(GridView g, unsigned hmax_q
             g.rec[(size_t)l * g.N + c] = rec_make(hmax_q, 2);
             g.len[c] = (uint8_t)(l + 1);
         }
+    }
+}
+
+// addLayer / removeTopLayer (script_columngrid.js:196-218) on one column of a grid in whole form.
+// op 0 appends (mat, z0q, z1q): a start above the column top takes a gap interval of its own,
+// a start below it cannot be held (flags[1]); flags[0] asks the host for more planes.
+// op 1 drops the top layer, and with it a gap it was resting on.
+__global__ void k_edit_column(GridView g, size_t c, int op, int mat, unsigned z0q, unsigned z1q, int* flags) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int l = g.len[c];
+    if (op == 0) {
+        const unsigned prev = l > 0 ? rec_z1(g.rec[(size_t)(l - 1) * g.N + c]) : 0u;
+        if (z0q < prev) { flags[1] = 1; return; }
+        const int need = z0q > prev ? 2 : 1;
+        if (l + need > g.lmax) { flags[0] = 1; return; }
+        if (z0q > prev) { g.rec[(size_t)l * g.N + c] = (z0q & 0xffffu) | REC_HOLE; l++; flags[2] = 1; }
+        g.rec[(size_t)l * g.N + c] = rec_make(z1q, mat); l++;
+        g.len[c] = (uint8_t)l;
+    } else {
+        if (l == 0) return;
+        l--; g.rec[(size_t)l * g.N + c] = 0;
+        if (l > 0 && rec_hole(g.rec[(size_t)(l - 1) * g.N + c])) { l--; g.rec[(size_t)l * g.N + c] = 0; }
+        g.len[c] = (uint8_t)l;
     }
 }
 

@@ -58,7 +58,7 @@ struct Snapshot {
     uint8_t* len = nullptr; uint32_t* rec = nullptr; uint32_t* top = nullptr; uint16_t* topz0 = nullptr;
     uint8_t* link = nullptr; uint8_t* prv = nullptr; int nextp = 0;
     bool split = true;
-    int lmax = 0; int len_bound = 0; bool has_gaps = false, has_cavity = false;
+    int lmax = 0; int lmax_vis = 0; int len_bound = 0; bool has_gaps = false, has_cavity = false;
 };
 
 struct Pending {
@@ -76,7 +76,8 @@ struct cg_grid {
     int nx = 0, ny = 0, nx_global = 0, i0 = 0;
     size_t N = 0;
     double dx = 0, dy = 0, zscale = 0.1;
-    int lmax = 32;
+    int lmax = 32;                                        // planes allocated
+    int lmax_vis = 32;                                    // the Lmax the reference would have now (stride of host-side arrays)
     uint8_t* len = nullptr; uint32_t* rec = nullptr;      // see cg_kernels.hip.h for the layout
     uint32_t* top = nullptr; uint16_t* topz0 = nullptr;   // split form: top interval of every column and its bottom
     uint32_t* top_alt = nullptr;                          // the buffer a lateral step writes its new tops to (then swapped)
@@ -283,6 +284,27 @@ int refresh_len_bound(cg_grid* g, unsigned* topq_out) {
     return CG_OK;
 }
 
+// The reference's Lmax: += 16 whenever an append finds its column full (script_columngrid.js:129-168,
+// 418; script_columngrid2.js:658).  Gaps take intervals of their own on the device but no slot in
+// the reference, so the planes (lmax) may outgrow it; only layers count here.
+int sync_vis(cg_grid* g) {
+    if (g->len_bound <= g->lmax_vis) return CG_OK;
+    int m = 0;
+    if (!g->has_gaps) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; m = g->len_bound; }
+    else {
+        int rc = ensure_whole(g); if (rc) return rc;
+        HIPCHK(g, hipMemsetAsync(g->d_red, 0, 2 * sizeof(unsigned), g->stream));
+        { ProfScope ps(g, CG_K_REDUCE);
+          hipLaunchKernelGGL(k_max_layers, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_red); }
+        unsigned r[2];
+        HIPCHK(g, hipMemcpyAsync(r, g->d_red, sizeof r, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        m = (int)r[0]; g->len_bound = (int)r[1];
+    }
+    while (m > g->lmax_vis) g->lmax_vis += 16;
+    return CG_OK;
+}
+
 const uint8_t* mask_ptr(cg_grid* g, int mask_id, bool* ok) {
     *ok = true;
     if (mask_id == CG_MASK_NONE) return nullptr;
@@ -448,7 +470,7 @@ int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
         }
     }
     if (g->len_bound < 255) g->len_bound += 1;
-    return CG_OK;
+    return sync_vis(g);
 }
 
 // New tops go to top_alt (the caller swaps the buffers when the step is complete).
@@ -552,7 +574,7 @@ int run_out_of_place(cg_grid* g, int which, const char* what, Launch launch) {
         if (fl[3] <= g->lmax) {
             swap_alt(g, which);
             g->len_bound = fl[3]; g->has_gaps = fl[2] != 0; g->has_cavity = fl[1] != 0;
-            return CG_OK;
+            return sync_vis(g);
         }
         rc = grow_planes(g, ((fl[3] - g->lmax + 15) / 16) * 16); if (rc) return rc;      // the spare set follows in ensure_alt
     }
@@ -697,6 +719,7 @@ int cg_create_slab(int nx_global, int ny, int i0, int nx_local, double dx, doubl
         HIPCHK(g, hipMemset(g->d_stats, 0, CG_NSTAT * sizeof(unsigned long long)));
         HIPCHK(g, hipEventCreate(&g->ev0)); HIPCHK(g, hipEventCreate(&g->ev1));
         int r = alloc_planes(g, lmax); if (r) return r;
+        g->lmax_vis = lmax;
         r = zero_planes(g); if (r) return r;
         HIPCHK(g, hipStreamSynchronize(g->stream));
         return CG_OK;
@@ -746,9 +769,10 @@ int cg_destroy(cg_grid* g) {
 
 int cg_reset(cg_grid* g, int lmax_init) {
     NEED(g);
-    int lmax = next_pow2(lmax_init > 0 ? lmax_init : g->lmax);
+    int lmax = next_pow2(lmax_init > 0 ? lmax_init : g->lmax_vis);
     if (lmax > 256) lmax = 256;
     g->pend.active = false;
+    g->lmax_vis = lmax;
     if (lmax != g->lmax) {
         HIPCHK(g, hipStreamSynchronize(g->stream));
         int rc = alloc_planes(g, lmax); if (rc) return rc;
@@ -761,7 +785,7 @@ int cg_clear(cg_grid* g) { NEED(g); g->pend.active = false; return zero_planes(g
 
 int cg_get_info(const cg_grid* g, cg_info* o) {
     if (!g || !o) return CG_ERR_ARG;
-    o->nx = g->nx; o->ny = g->ny; o->nx_global = g->nx_global; o->i0 = g->i0; o->lmax = g->lmax; o->device = g->device;
+    o->nx = g->nx; o->ny = g->ny; o->nx_global = g->nx_global; o->i0 = g->i0; o->lmax = g->lmax_vis; o->device = g->device;
     o->dx = g->dx; o->dy = g->dy; o->zscale = g->zscale;
     o->offset_x = -(g->nx_global - 1) * g->dx / 2; o->offset_y = -(g->ny - 1) * g->dy / 2;
     o->lx_eff = g->nx_global * g->dx; o->ly_eff = g->ny * g->dy;
@@ -956,6 +980,7 @@ int cg_stencil_finish(cg_grid* g) {
     }
     std::swap(g->top, g->top_alt);
     if (g->len_bound < 255) g->len_bound += 1;
+    rc = sync_vis(g); if (rc) return rc;
     // identify_cavity (cg1:543) -- a no-op while no column has a vertical gap.  On a slab the
     // driver runs it over all slabs (the decision and the flood are whole-domain matters).
     if ((g->has_gaps || g->has_cavity) && g->nx == g->nx_global) return cg_identify_cavity(g);
@@ -1131,7 +1156,7 @@ int cg_cavity_fill(cg_grid* g, uint32_t hmax_q) {
     }
     if (g->len_bound < 255) g->len_bound += 1;
     g->has_cavity = true;
-    return CG_OK;
+    return sync_vis(g);         // only past the point where the reference has overrun its own arrays (cg2:41-66)
 }
 
 int cg_identify_cavity(cg_grid* g) {
@@ -1312,7 +1337,7 @@ int cg_ald_increment(cg_grid* g, int mat, double t) {
         if (fl[3] <= g->lmax) {
             swap_alt(g, 1);
             g->len_bound = fl[3]; g->has_gaps = fl[2] != 0; g->has_cavity = fl[1] != 0;
-            return CG_OK;
+            return sync_vis(g);
         }
         rc = grow_planes(g, ((fl[3] - g->lmax + 15) / 16) * 16); if (rc) return rc;
     }
@@ -1350,11 +1375,45 @@ int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q) {
     return CG_OK;
 }
 
+// ---- single-column accessors (script_columngrid.js:196-218) ---------------------------------
+static int edit_column(cg_grid* g, int i, int j, int op, int mat, unsigned z0q, unsigned z1q) {
+    if (i < 0 || i >= g->nx || j < 0 || j >= g->ny) return fail(g, CG_ERR_ARG, "column (%d, %d) is outside the %d x %d grid", i, j, g->nx, g->ny);
+    g->pend.active = false;
+    int rc = ensure_whole(g); if (rc) return rc;
+    const size_t c = (size_t)i * g->ny + j;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+        hipLaunchKernelGGL(k_edit_column, dim3(1), dim3(64), 0, g->stream, view(g), c, op, mat, z0q, z1q, g->d_flags);
+        HIPCHK(g, hipGetLastError());
+        int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
+        if (fl[1]) return fail(g, CG_ERR_UNSUPPORTED, "addLayer: the layer starts below the top of column (%d, %d)", i, j);
+        if (fl[2]) g->has_gaps = true;
+        if (!fl[0]) break;
+        if (attempt || g->lmax >= 256) return fail(g, CG_ERR_UNSUPPORTED, "addLayer: column (%d, %d) is full", i, j);
+        rc = grow_planes(g); if (rc) return rc;                 // script_columngrid.js:199
+    }
+    if (op == 0) { g->len_bound = std::min(255, g->len_bound + 2); if (mat == CG_MAT_CAVITY) g->has_cavity = true; return sync_vis(g); }
+    return CG_OK;
+}
+
+int cg_add_layer(cg_grid* g, int i, int j, int mat, double z0_nm, double z1_nm) {
+    NEED(g);
+    if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "bad material id %d", mat);
+    const unsigned q0 = (unsigned)js_to_int32(js_round(z0_nm / g->zscale)) & 0xffffu;       // _quantizeZ, stored as Uint16
+    const unsigned q1 = (unsigned)js_to_int32(js_round(z1_nm / g->zscale)) & 0xffffu;
+    return edit_column(g, i, j, 0, mat, q0, q1);
+}
+
+int cg_remove_top_layer(cg_grid* g, int i, int j) {
+    NEED(g);
+    return edit_column(g, i, j, 1, 0, 0, 0);
+}
+
 // ---- host exchange --------------------------------------------------------------------------
 int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
     NEED(g);
     if (!mat || !zpair || !len) return fail(g, CG_ERR_ARG, "null output array");
-    const int L = g->lmax;
+    const int L = g->lmax_vis;
     const size_t chunk = std::min<size_t>(g->N, (size_t)1 << 20);
     uint8_t *dm = nullptr, *dl = nullptr; uint16_t* dz = nullptr;
     HIPCHK(g, hipMalloc(&dm, chunk * L)); HIPCHK(g, hipMalloc(&dz, chunk * L * 4)); HIPCHK(g, hipMalloc(&dl, chunk));
@@ -1377,6 +1436,7 @@ int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8
     g->pend.active = false;
     HIPCHK(g, hipStreamSynchronize(g->stream));
     if (lmax != g->lmax) { int rc = alloc_planes(g, lmax); if (rc) return rc; }
+    g->lmax_vis = lmax;
     g->split = false;                                       // the scatter kernel writes whole stacks
     const int L = lmax;
     const size_t chunk = std::min<size_t>(g->N, (size_t)1 << 20);
@@ -1424,7 +1484,7 @@ int cg_snapshot_save(cg_grid* g, int slot) {
     HIPCHK(g, hipMemcpyAsync(s.top, g->top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(s.topz0, g->topz0, 2 * g->N, hipMemcpyDeviceToDevice, g->stream));
     s.split = g->split;
-    s.lmax = g->lmax; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps; s.has_cavity = g->has_cavity;
+    s.lmax = g->lmax; s.lmax_vis = g->lmax_vis; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps; s.has_cavity = g->has_cavity;
     g->snaps[slot] = s;
     return CG_OK;
 }
@@ -1446,6 +1506,7 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     g->nextp = s.nextp;
     g->split = s.split;
     g->len_bound = s.len_bound; g->has_gaps = s.has_gaps; g->has_cavity = s.has_cavity;
+    g->lmax_vis = s.lmax_vis;
     return CG_OK;
 }
 
@@ -1464,7 +1525,7 @@ int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count, void
     NEED(g);
     if ((axis != 0 && axis != 1) || !index || count < 1) return fail(g, CG_ERR_ARG, "bad slice request");
     const size_t line = axis == 0 ? (size_t)g->ny : (size_t)g->nx;
-    const int L = g->lmax;
+    const int L = g->lmax_vis;
     const size_t need = line * count;
     for (int s = 0; s < count; s++) {
         const int lim = axis == 0 ? g->nx : g->ny;
@@ -1495,7 +1556,7 @@ int cg_slices(cg_grid* g, int axis, const int32_t* index, int count, uint8_t* ma
     if (!mat || !zpair || !len) return fail(g, CG_ERR_ARG, "null output array");
     int rc = cg_slices_device(g, axis, index, count, nullptr, nullptr, nullptr); if (rc) return rc;
     const size_t line = axis == 0 ? (size_t)g->ny : (size_t)g->nx;
-    const size_t n = line * count; const int L = g->lmax;
+    const size_t n = line * count; const int L = g->lmax_vis;
     HIPCHK(g, hipMemcpyAsync(mat, g->sl_mat, n * L, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(g, hipMemcpyAsync(zpair, g->sl_zp, n * L * 4, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(g, hipMemcpyAsync(len, g->sl_len, n, hipMemcpyDeviceToHost, g->stream));

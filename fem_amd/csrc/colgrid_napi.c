@@ -286,6 +286,25 @@ static napi_value js_release_scratch(napi_env env, napi_callback_info info) {   
     return undefined(env);
 }
 
+/* ---- single-column accessors ------------------------------------------------------------------ */
+static napi_value js_add_layer(napi_env env, napi_callback_info info) {          /* cg_add_layer */
+    ARGS(env, info, 6);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t i, j, mat; double z0, z1;
+    if (!get_int(env, argv[1], &i) || !get_int(env, argv[2], &j) || !get_int(env, argv[3], &mat) ||
+        !get_double(env, argv[4], &z0) || !get_double(env, argv[5], &z1)) return NULL;
+    int rc = cg_add_layer(g, i, j, mat, z0, z1); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+static napi_value js_remove_top_layer(napi_env env, napi_callback_info info) {   /* cg_remove_top_layer */
+    ARGS(env, info, 3);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t i, j;
+    if (!get_int(env, argv[1], &i) || !get_int(env, argv[2], &j)) return NULL;
+    int rc = cg_remove_top_layer(g, i, j); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+
 /* ---- data exchange ------------------------------------------------------------------------- */
 static napi_value js_download(napi_env env, napi_callback_info info) {           /* cg_download */
     ARGS(env, info, 1);
@@ -385,6 +404,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"etchWetStep", js_etch_wet_step}, {"etchWet", js_etch_wet}, {"depositAld", js_deposit_ald},
         {"aldCollectSeeds", js_ald_collect_seeds}, {"aldDropSeeds", js_ald_drop_seeds}, {"aldIncrement", js_ald_increment},
         {"aldCoat", js_ald_coat}, {"releaseScratch", js_release_scratch},
+        {"addLayer", js_add_layer}, {"removeTopLayer", js_remove_top_layer},
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;

@@ -229,6 +229,12 @@ class ColumnGrid {
   }
 
   // ---- accessors kept for API parity (cg1:174-218)
+  addLayer(i, j, matId, z0_real, z1_real) {                                                               // cg1:196
+    addon.addLayer(this._h, i | 0, j | 0, matId & 255, Number(z0_real), Number(z1_real)); this._touched();
+  }
+  removeTopLayer(i, j) { addon.removeTopLayer(this._h, i | 0, j | 0); this._touched(); }                  // cg1:213
+  _nextPowerOf2(n) { return 1 << (32 - Math.clz32(Math.max(1, n - 1))); }                                 // cg1:302
+  _clamp(v, lo, hi) { return Math.max(lo, Math.min(hi, v)); }                                             // cg1:309
   getLen(i, j) { return this.cols.len[this._colIndex(i, j)]; }
   topMat(i, j) { const c = this._colIndex(i, j), l = this.cols.len[c]; return l === 0 ? 0 : this.cols.mat[c * this.Lmax + l - 1]; }
   topZ(i, j) { const c = this._colIndex(i, j), l = this.cols.len[c]; return l === 0 ? 0 : this._dequantizeZ(this.cols.zpair[(c * this.Lmax + l - 1) * 2 + 1]); }

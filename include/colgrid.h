@@ -55,7 +55,9 @@ typedef struct cg_info {
     int32_t nx, ny;            /* columns owned by this handle (a slab when nx < nx_global)  */
     int32_t nx_global;         /* NX of the whole domain                                      */
     int32_t i0;                /* global i index of local row 0                               */
-    int32_t lmax;              /* layers per column currently provisioned (reference: Lmax)   */
+    int32_t lmax;              /* the reference's Lmax for this history: += 16 each time an append
+                                * finds its column full (cg1:129-168, 418); stride of cg_download.
+                                * The planes the device holds may be more (gaps take intervals). */
     int32_t device;            /* HIP device ordinal                                          */
     double  dx, dy, zscale;
     double  offset_x, offset_y, lx_eff, ly_eff;   /* of the whole domain                      */
@@ -217,6 +219,16 @@ int cg_ald_coat(cg_grid* g, int mat, double t);
 /* Frees the second and third set of planes that etch_wet / deposit_ALD steps work in
  * (they are as large as the grid itself).  No counterpart in the reference. */
 int cg_release_scratch(cg_grid* g);
+
+/* addLayer(i, j, matId, z0, z1) (cg1:196-211): appends one layer to column (i, j), heights
+ * quantised like _quantizeZ and stored as Uint16; grows the planes when the column is full
+ * (cg1:199).  A layer that starts above the column top leaves a gap below it, as in the
+ * reference; one that starts BELOW the top cannot be held by the engine's gapless intervals
+ * and is refused with CG_ERR_UNSUPPORTED (no reference step produces such a column).
+ * removeTopLayer(i, j) (cg1:213-218): drops the top layer; no-op on an empty column.  The freed
+ * slot reads back as zeros (the reference leaves its old bytes there until it is reused). */
+int cg_add_layer(cg_grid* g, int i, int j, int mat, double z0_nm, double z1_nm);
+int cg_remove_top_layer(cg_grid* g, int i, int j);
 
 /* maxHeight() (cg2:85-104): max top z over this handle's columns in nm, 1 if that is 0.
  * top_q receives the quantised maximum (0 for an empty grid); either pointer may be NULL. */

@@ -150,6 +150,27 @@ static void og_expand(og_grid *g) {
     g->mat = nm; g->zpair = nz; g->Lmax = newL;
 }
 
+/* ---- addLayer / removeTopLayer, cg1:196-218 ---------------------------------------------- */
+int og_add_layer(og_grid *g, int i, int j, int matId, double z0, double z1) {
+    size_t cidx = (size_t)i * g->NY + j;
+    int l = g->len[cidx];
+    if (l >= g->Lmax) og_expand(g);
+    size_t base = cidx * g->Lmax + l;
+    g->mat[base] = (uint8_t)matId;
+    g->zpair[base * 2] = to_u16(quantZ(g, z0));
+    g->zpair[base * 2 + 1] = to_u16(quantZ(g, z1));
+    g->len[cidx] = (uint8_t)(l + 1);
+    return 0;
+}
+
+int og_remove_top_layer(og_grid *g, int i, int j) {          /* the slot keeps its bytes (cg1:213-218) */
+    size_t cidx = (size_t)i * g->NY + j;
+    int l = g->len[cidx];
+    if (l == 0) return 0;
+    g->len[cidx] = (uint8_t)(l - 1);
+    return 0;
+}
+
 /* ---- _depoAtTop_, cg1:397-426 --------------------------------------------------------- */
 static void depo_at_top(og_grid *g, size_t cidx, int matId, double dz) {
     if (dz <= 0) return;

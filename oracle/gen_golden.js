@@ -86,9 +86,12 @@ function runCase(name, domain, masks, steps, opts = {}) {
       case 'etch_wet': g.etch_wet(s.mat, s.t, s.dt === undefined ? { isCache: !!s.isCache } : { isCache: !!s.isCache, dt: s.dt }); break;
       case 'deposit_ALD': g.deposit_ALD(s.mat, s.t, s.dt === undefined ? { isCache: !!s.isCache } : { isCache: !!s.isCache, dt: s.dt }); break;
       case 'slider_reset': g.sliderCache = {}; break;
+      case 'addLayer': g.addLayer(s.i, s.j, s.mat, s.z0, s.z1); break;
+      case 'removeTopLayer': g.removeTopLayer(s.i, s.j); break;
       default: throw new Error('unknown op ' + s.op);
     }
     const rec = Object.assign({}, s, { fnv: H.gridHash(g), lmax: g.Lmax, max_height: g.maxHeight() });
+    if (s.i !== undefined) rec.probe = [g.getLen(s.i, s.j), g.topMat(s.i, s.j), g.topZ(s.i, s.j)];
     if (g.sliderCache && (g.sliderCache.aldCache || g.sliderCache.wetetchCache)) {
       const a = g.sliderCache.aldCache, w = g.sliderCache.wetetchCache;
       rec.slider = { ald_keys: a ? Array.from(a.gridWithCavity.keys()) : [], seeds: a && a.exposedSegments ? a.exposedSegments.length : 0,
@@ -235,6 +238,20 @@ const etc = (mask, mat, t, S = 0, dump = false) => ({ op: 'etch_general', mask, 
     dep('all', 3, 20, 0), dep('all', 4, 1, 0), dep('all', 5, 0.5, 0), dep('all', 4, 0.7, 0), dep('all', 5, 1.3, 0), dep('all', 4, 0.4, 0),
     dep('all', 5, 9, 0), etc('trench', 255, 20, 0, true), wet(4, 4), ald(6, 1.1, { dt: 0.5 }), ald(7, 2.9), wet(5, 1.2, { dt: 0.4 }),
     ald(3, 0.3), wet(255, 0.7),
+  ]);
+}
+
+// 7b. single-column accessors (cg1:174-218) mixed with steps: layers resting on the top, layers that
+//     leave a gap (the next conformal deposit turns it into a cavity), a removed layer whose slot
+//     is reused before the dump, growth through addLayer on a full column (Lmax 2 -> 18)
+{
+  const add = (i, j, mat, z0, z1) => ({ op: 'addLayer', i, j, mat, z0, z1 });
+  const rem = (i, j) => ({ op: 'removeTopLayer', i, j });
+  runCase('accessors_small', Object.assign(D(48, 40), { Lmax: 2 }), { half: { objects: [rect(0, 0, 20, 100)] } }, [
+    rem(0, 0), dep('all', 3, 10, 0), add(3, 4, 4, 10, 12.34), add(3, 5, 4, 12, 15), add(3, 5, 5, 15, 15.05), add(3, 5, 6, 15.05, 16),
+    add(10, 10, 3, 10, 11), add(23, 19, 5, 14.96, 18.04), rem(3, 4), add(3, 4, 7, 10, 11.5), rem(10, 10), add(10, 10, 4, 10, 10.5),
+    dep(null, 4, 4, 1.0, true), etc('half', 255, 3, 0), rem(23, 19), add(23, 19, 6, 30, 31), etc(null, 4, 2, 1.0),
+    { op: 'strip_connected', mat: 6 }, { op: 'cmp', t: 3, mat: 0 },
   ]);
 }
 

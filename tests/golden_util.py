@@ -8,7 +8,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 STEP_CASES = ["vertical_small", "stencil_small", "stencil_odd", "anchor_256", "masks_small",
-              "growth_small", "cavity_small", "kcache_small", "wet_ald_small", "wet_ald_cache", "wet_ald_thin"]
+              "growth_small", "cavity_small", "kcache_small", "wet_ald_small", "wet_ald_cache", "wet_ald_thin", "accessors_small"]
 
 
 def load_case(name):
@@ -66,6 +66,10 @@ def run_steps(grid, case, mask_of, on_step=None):
             grid.deposit_ALD(s["mat"], s["t"], dt=s.get("dt"), isCache=s.get("isCache", False))
         elif op == "slider_reset":
             grid.slider_reset()
+        elif op == "addLayer":
+            grid.addLayer(s["i"], s["j"], s["mat"], s["z0"], s["z1"])
+        elif op == "removeTopLayer":
+            grid.removeTopLayer(s["i"], s["j"])
         else:
             raise ValueError(op)
         if on_step:

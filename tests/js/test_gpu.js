@@ -20,12 +20,12 @@ function fnv(grid) {
 const same = (a, b, what) => { assert.strictEqual(a.length, b.length, what + ' length'); for (let k = 0; k < a.length; k++) if (a[k] !== b[k]) assert.fail(`${what} differs at ${k}: ${a[k]} vs ${b[k]}`); };
 
 for (const name of ['vertical_small', 'stencil_small', 'stencil_odd', 'masks_small', 'growth_small', 'cavity_small', 'kcache_small', 'anchor_256',
-  'wet_ald_small', 'wet_ald_cache', 'wet_ald_thin']) {
+  'wet_ald_small', 'wet_ald_cache', 'wet_ald_thin', 'accessors_small']) {
   const c = JSON.parse(fs.readFileSync(path.join(GOLD, name + '.json')));
   const binPath = path.join(GOLD, name + '.bin.gz');
   const bin = fs.existsSync(binPath) ? zlib.gunzipSync(fs.readFileSync(binPath)) : null;
   const d = c.domain;
-  const g = new ColumnGrid(d.LX, d.LY, d.dx, d.dy);
+  const g = new ColumnGrid(d.LX, d.LY, d.dx, d.dy, d.Lmax === undefined ? 32 : d.Lmax, d.zScale === undefined ? 0.1 : d.zScale);
   assert.strictEqual(g.NX, c.nx); assert.strictEqual(g.NY, c.ny);
   const n = g.NX * g.NY;
   let off = 0;
@@ -43,6 +43,8 @@ for (const name of ['vertical_small', 'stencil_small', 'stencil_odd', 'masks_sma
       case 'etch_wet': g.etch_wet(s.mat, s.t, s.dt === undefined ? { isCache: !!s.isCache } : { isCache: !!s.isCache, dt: s.dt }); break;
       case 'deposit_ALD': g.deposit_ALD(s.mat, s.t, s.dt === undefined ? { isCache: !!s.isCache } : { isCache: !!s.isCache, dt: s.dt }); break;
       case 'slider_reset': g.sliderCache = {}; break;
+      case 'addLayer': g.addLayer(s.i, s.j, s.mat, s.z0, s.z1); break;
+      case 'removeTopLayer': g.removeTopLayer(s.i, s.j); break;
       default: throw new Error(s.op);
     }
     if (s.slider) {
@@ -52,6 +54,7 @@ for (const name of ['vertical_small', 'stencil_small', 'stencil_odd', 'masks_sma
       assert.strictEqual(a && a.exposedSegments ? a.exposedSegments.count : 0, s.slider.seeds, `${name} step ${idx} seeds`);
       assert.strictEqual(w ? w.R : 0, s.slider.wet_R, `${name} step ${idx} wet R`);
     }
+    if (s.probe) assert.deepStrictEqual([g.getLen(s.i, s.j), g.topMat(s.i, s.j), g.topZ(s.i, s.j)], s.probe, `${name} step ${idx} probe`);
     assert.strictEqual(g.maxHeight(), s.max_height, `${name} step ${idx} maxHeight`);
     if (s.dump_index !== undefined) {
       const lm = c.dumps[s.dump_index].lmax;

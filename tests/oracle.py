@@ -59,6 +59,8 @@ def _lib():
     L.og_strip_connected.argtypes = [vp, i]
     L.og_identify_cavity.argtypes = [vp]
     L.og_cmp.argtypes = [vp, d, i]
+    L.og_add_layer.argtypes = [vp, i, i, i, d, d]
+    L.og_remove_top_layer.argtypes = [vp, i, i]
     L.og_mask_raster.argtypes = [vp, vp, i, vp, vp]
     L.og_checksum.restype = C.c_uint64; L.og_checksum.argtypes = [vp]
     L.og_fnv.restype = C.c_uint32; L.og_fnv.argtypes = [vp]
@@ -152,6 +154,12 @@ class OracleGrid:
 
     def reset(self, lmax=0):
         self.L.og_reset(self.h, lmax)
+
+    def addLayer(self, i, j, mat, z0, z1):
+        self.L.og_add_layer(self.h, i, j, mat, z0, z1)
+
+    def removeTopLayer(self, i, j):
+        self.L.og_remove_top_layer(self.h, i, j)
 
     def etch_wet(self, mat, t, dt=None, isCache=False):
         rc = self.L.og_etch_wet(self.h, mat, t, float("nan") if dt is None else dt, int(bool(isCache)))

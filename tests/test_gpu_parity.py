@@ -52,6 +52,11 @@ def test_golden_steps(name):
         assert g.maxHeight() == s["max_height"], f"{name} step {idx}"
         if "slider" in s:
             assert g.slider_sizes() == (len(s["slider"]["ald_keys"]), len(s["slider"]["wet_keys"]), s["slider"]["seeds"])
+        if "probe" in s:                                  # getLen / topMat / topZ of the edited column
+            ln, mat, zp = g.download()
+            c = s["i"] * g.NY + s["j"]; l = int(ln[c]); top = c * g.Lmax + l - 1
+            got = [l, int(mat[top]) if l else 0, float(zp[2 * top + 1]) * case["domain"].get("zScale", 0.1) if l else 0]
+            assert got == s["probe"], f"{name} step {idx} probe"
         if "dump_index" in s:
             ln, mat, zp, lm = case["dump_arrays"][s["dump_index"]]
             _assert_same(g, (ln, mat, zp), f"{name} step {idx} {s['op']}")
@@ -326,11 +331,40 @@ def test_same_material_runs_across_gaps_and_form_changes():
         assert g.checksum() == o.checksum()
         for args in (("e", None, 3, 5, 1.0), ("d", None, 3, 2.2, 0), ("e", 1, 255, 11, 0), ("d", None, 7, 6, 1.0)):
             step(*args)
-    ln, mat, zp = g.download(); oln, omat, ozp = o.arrays()
-    L0 = min(g.Lmax, o.Lmax)
-    np.testing.assert_array_equal(ln, oln)
-    np.testing.assert_array_equal(mat.reshape(-1, g.Lmax)[:, :L0], omat.reshape(-1, o.Lmax)[:, :L0])
-    np.testing.assert_array_equal(zp.reshape(-1, g.Lmax, 2)[:, :L0], ozp.reshape(-1, o.Lmax, 2)[:, :L0])
+    assert g.Lmax == o.Lmax
+    _assert_same(g, o.arrays(), "final")
+    g.close()
+
+
+def test_lmax_follows_the_reference_while_columns_have_gaps():
+    """A stripped layer leaves a gap that takes an interval on the device but no slot in the
+    reference's arrays: the Lmax the engine reports (and the stride of what it downloads) has to
+    grow when the reference's would, not when the device runs out of planes."""
+    fem = _engine()
+    nx, ny = 48, 40
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2, 4)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2, 4)
+    trench = np.zeros((nx, ny), np.uint8); trench[20:28, :] = 1
+    gm = g.mask_from_raster(trench.reshape(-1)); om = trench.reshape(-1)
+    seen = []
+    for k, (kind, m, mat, t) in enumerate([("d", None, 3, 10), ("d", None, 4, 5), ("d", None, 5, 5), ("e", 1, 255, 12), ("s", None, 4, 0),
+                                           ("d", None, 6, 2), ("d", None, 7, 2), ("d", None, 8, 2), ("e", None, 8, 1), ("d", None, 6, 1),
+                                           ("d", None, 7, 1)]):
+        for grid, mk in ((g, gm if m else None), (o, om if m else None)):
+            if kind == "d":
+                grid.deposit_general(mk, mat, t, 0)
+            elif kind == "e":
+                grid.etch_general(mk, mat, t, 0)
+            else:
+                grid.strip_connected(mat)
+        assert g.Lmax == o.Lmax, f"step {k}: Lmax {g.Lmax} vs {o.Lmax}"
+        _assert_same(g, o.arrays(), f"step {k}")
+        seen.append(o.Lmax)
+    assert seen[0] == 4 and seen[-1] > 4 and (o.arrays()[0].max() < g.Lmax + 1)
+    g.snapshot_save(3)
+    g.deposit_general(None, 3, 1, 0); g.snapshot_load(3)
+    assert g.Lmax == o.Lmax
+    _assert_same(g, o.arrays(), "after snapshot")
     g.close()
 
 

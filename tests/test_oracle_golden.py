@@ -41,6 +41,12 @@ def test_steps_match_reference(name):
         if "slider" in s:
             na, nw, nseed = g.slider_sizes()
             assert (na, nw, nseed) == (len(s["slider"]["ald_keys"]), len(s["slider"]["wet_keys"]), s["slider"]["seeds"])
+        if "probe" in s:                                  # getLen / topMat / topZ of the edited column
+            oln, omat, ozp = g.arrays()
+            c = s["i"] * g.NY + s["j"]; l = int(oln[c])
+            top = (c * g.Lmax + l - 1)
+            got = [l, int(omat[top]) if l else 0, float(ozp[2 * top + 1]) * case["domain"].get("zScale", 0.1) if l else 0]
+            assert got == s["probe"], f"{name} step {idx} probe"
         if "dump_index" in s:
             ln, mat, zp, lm = case["dump_arrays"][s["dump_index"]]
             oln, omat, ozp = g.arrays()
