@@ -95,6 +95,7 @@ ABI = {
     "cg_stencil_begin": (_i, [_vp, _i, _i, _i, _d, _d, _i, _i, C.POINTER(_i)]),
     "cg_halo_buffers": (_i, [_vp, _pp, _pp, _pp, _pp, C.POINTER(_sz)]),
     "cg_stencil_finish": (_i, [_vp]),
+    "cg_stencil_interior": (_i, [_vp]),
     "cg_set_halo_buffers": (_i, [_vp, _vp, _vp, _vp, _vp, _sz]),
     "cg_profile": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_uint64)]),
     "cg_download": (_i, [_vp, _vp, _vp, _vp]),
@@ -535,6 +536,10 @@ class ColumnGrid:
 
     def stencil_finish(self):
         self._chk(self.lib.cg_stencil_finish(self.h))
+
+    def stencil_interior(self):
+        """The part of an open lateral step that needs no halo row (overlaps with the exchange)."""
+        self._chk(self.lib.cg_stencil_interior(self.h))
 
     def set_halo_buffers(self, send_lower, send_upper, recv_lower, recv_upper, bytes_each):
         self._chk(self.lib.cg_set_halo_buffers(self.h, send_lower, send_upper, recv_lower, recv_upper, bytes_each))

@@ -55,6 +55,7 @@ struct GridView {
     int       nx, ny;
     int       lmax;     // planes provisioned
     int       i0;       // global row of local row 0
+    int       tile_i0;  // lateral steps: tile row of block 0 (a launch may cover a band of tile rows)
     double    zs;       // nm per step
     double    inv_zs;   // 1/zs, rounded once on the host
 };
@@ -537,7 +538,8 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
     const int pitch = TJ + 2 * R;
     const int tile_rows = TI + 2 * R;
     const int tiles_j = (g.ny + TJ - 1) / TJ;
-    const int tile_i = blockIdx.x / tiles_j, tile_j = (blockIdx.x % tiles_j + tile_i) % tiles_j;
+    const int bi = blockIdx.x / tiles_j;
+    const int tile_i = g.tile_i0 + bi, tile_j = (blockIdx.x - bi * tiles_j + tile_i) % tiles_j;
     const int i_base = tile_i * TI, j_base = tile_j * TJ;
 
     // ---- stage heights (as float32 of q*zscale, cg1:465) with halo; flags fold into +inf
@@ -695,7 +697,8 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
     const int tiles_j = (g.ny + TJS - 1) / TJS;
     // rotate the column tile by the row tile so that one XCD (blockIdx mod 8) does not always get
     // the same column range (see k_vertical_g4)
-    const int tile_i = blockIdx.x / tiles_j, tile_j = (blockIdx.x - tile_i * tiles_j + tile_i) % tiles_j;
+    const int bi = blockIdx.x / tiles_j;
+    const int tile_i = g.tile_i0 + bi, tile_j = (blockIdx.x - bi * tiles_j + tile_i) % tiles_j;
     const int i_base = tile_i * TIS, j_base = tile_j * TJS;
     const float INF = __builtin_inff();
 

@@ -67,6 +67,7 @@ struct Pending {
     double t_eff = 0;
     ConfKernel* K = nullptr;
     bool has_lower = false, has_upper = false;
+    bool interior_done = false, may_overflow = false; int P = -1;     // set by cg_stencil_interior
 };
 
 }  // namespace
@@ -175,7 +176,7 @@ GridView view(const cg_grid* g) {
     GridView v;
     v.len = g->len; v.rec = g->rec; v.top = g->top; v.top_w = g->top; v.topz0 = g->topz0; v.split = g->split ? 1 : 0;
     v.link = g->link; v.prv = g->prv; v.P = -1;
-    v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
+    v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.tile_i0 = 0; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
     return v;
 }
 
@@ -474,13 +475,29 @@ int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
 }
 
 // New tops go to top_alt (the caller swaps the buffers when the step is complete).
+// part: PART_ALL every tile; PART_INTERIOR the tile rows whose stencil stays inside the slab
+// (they need no halo message); PART_BOUNDARY the others.
+enum { PART_ALL = 0, PART_INTERIOR = 1, PART_BOUNDARY = 2 };
+struct Band { int t0, n; };
+static int stencil_bands(int nx, int th, int R, bool has_lower, bool has_upper, int part, Band out[2]) {
+    const int ntr = (nx + th - 1) / th;
+    int lo = has_lower ? std::min(ntr, (R + th - 1) / th) : 0;              // tile rows reaching below row 0
+    int up = has_upper ? std::max(lo, std::min(ntr, std::max(0, (nx - R) / th))) : ntr;   // first tile row reaching past row nx-1
+    if (part == PART_ALL) { out[0] = {0, ntr}; return 1; }
+    if (part == PART_INTERIOR) { out[0] = {lo, up - lo}; return up > lo ? 1 : 0; }
+    int n = 0;
+    if (lo > 0) out[n++] = {0, lo};
+    if (ntr > up) out[n++] = {up, ntr - up};
+    return n;
+}
+
 int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t_eff, int R, ConfKernel* K, int only_len,
-                   const uint8_t* halo_lo, const uint8_t* halo_up, int P) {
+                   const uint8_t* halo_lo, const uint8_t* halo_up, int P, int part = PART_ALL) {
     GridView gv = view(g);
     gv.top_w = g->top_alt; gv.P = P;
-    const int tiles = ((g->nx + TI - 1) / TI) * ((g->ny + TJ - 1) / TJ);
     const size_t lds = stencil_lds_bytes(R);
-    const dim3 grid(tiles), blk(256);
+    const dim3 blk(256);
+    Band bands[2];
     ProfScope ps(g, etch ? CG_K_STENCIL_ETCH : CG_K_STENCIL_DEPOSIT);
     if (only_len < 0 && K->sym_ok && g->ny % 4 == 0 && !getenv("CG_NO_SYM")) {
         const int tjs = sym_tile_cols();
@@ -492,9 +509,13 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
             for (int dv_ = 0; dv_ <= RR; dv_++) if (tab.a[du_ * (RR + 1) + dv_] != -INFINITY) tab.lim[du_] = dv_; \
         }                                                                                                      \
         const int tis = 1024 / TT;                                                                             \
-        const dim3 gridS(((g->nx + tis - 1) / tis) * ((g->ny + TT - 1) / TT));                                 \
-        hipLaunchKernelGGL((k_stencil_sym<RR, TT, E, S>), gridS, blk, 0, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
-                           tab, K->d_taps64_sym, K->ntaps64_sym, g->d_flags, g->d_stats);                      \
+        const int nb = stencil_bands(g->nx, tis, R, halo_lo != nullptr, halo_up != nullptr, part, bands);      \
+        for (int b_ = 0; b_ < nb; b_++) {                                                                      \
+            gv.tile_i0 = bands[b_].t0;                                                                         \
+            const dim3 gridS(bands[b_].n * ((g->ny + TT - 1) / TT));                                           \
+            hipLaunchKernelGGL((k_stencil_sym<RR, TT, E, S>), gridS, blk, 0, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
+                               tab, K->d_taps64_sym, K->ntaps64_sym, g->d_flags, g->d_stats);                  \
+        }                                                                                                      \
     } while (0)
 #define SYM_T(RR, E, S) do { if (tjs == 64) SYM(RR, 64, E, S); else if (tjs == 128) SYM(RR, 128, E, S); else SYM(RR, 256, E, S); } while (0)
 #define SYM_ES(RR)                                                                                             \
@@ -516,8 +537,13 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
     do {                                                                                                       \
         if (lds > 48 * 1024)                                                                                   \
             HIPCHK(g, hipFuncSetAttribute((const void*)k_stencil_apply<E, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_stencil_apply<E, S>), grid, blk, lds, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
-                           K->d_taps, K->ntaps, K->d_taps64, K->ntaps64, only_len, g->d_flags, g->d_stats);    \
+        const int nb = stencil_bands(g->nx, TI, R, halo_lo != nullptr, halo_up != nullptr, part, bands);       \
+        for (int b_ = 0; b_ < nb; b_++) {                                                                      \
+            gv.tile_i0 = bands[b_].t0;                                                                         \
+            const dim3 grid(bands[b_].n * ((g->ny + TJ - 1) / TJ));                                            \
+            hipLaunchKernelGGL((k_stencil_apply<E, S>), grid, blk, lds, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
+                               K->d_taps, K->ntaps, K->d_taps64, K->ntaps64, only_len, g->d_flags, g->d_stats); \
+        }                                                                                                      \
     } while (0)
     if (etch) { if (g->stats_on) LAUNCH(true, true); else LAUNCH(true, false); }
     else { if (g->stats_on) LAUNCH(false, true); else LAUNCH(false, false); }
@@ -917,6 +943,7 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     g->pend.active = true; g->pend.kind = kind; g->pend.mask_id = mask_id; g->pend.mat = mat; g->pend.R = R; g->pend.K = K;
     g->pend.t_eff = (kind == CG_STENCIL_DEPOSIT) ? K->baseAdd : t;        // cg1:470/499 vs cg1:702
     g->pend.has_lower = has_lower != 0; g->pend.has_upper = has_upper != 0;
+    g->pend.interior_done = false; g->pend.may_overflow = false; g->pend.P = -1;
     if (radius_rows) *radius_rows = R;
     return CG_OK;
 }
@@ -948,34 +975,59 @@ int cg_set_halo_buffers(cg_grid* g, void* send_lower, void* send_upper, void* re
     return CG_OK;
 }
 
+// What a deposit has to settle before its first launch: the overflow watch and the plane it
+// pushes old tops into (one for the whole step, however many launches it takes).
+static int stencil_prepare_deposit(cg_grid* g) {
+    Pending& p = g->pend;
+    p.may_overflow = g->len_bound >= g->lmax;
+    if (p.may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; p.may_overflow = g->len_bound >= g->lmax; }
+    if (p.may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
+    return take_append_plane(g, &p.P);
+}
+
+int cg_stencil_interior(cg_grid* g) {
+    NEED(g);
+    if (!g->pend.active) return fail(g, CG_ERR_STATE, "no stencil step is open");
+    if (g->pend.interior_done) return fail(g, CG_ERR_STATE, "the interior of this step has been launched already");
+    if (!g->pend.has_lower && !g->pend.has_upper) return CG_OK;            // nothing is in flight: finish does it all
+    bool ok; const uint8_t* mask = mask_ptr(g, g->pend.mask_id, &ok);
+    if (!ok) return fail(g, CG_ERR_ARG, "mask %d vanished during the step", g->pend.mask_id);
+    const bool etch = g->pend.kind == CG_STENCIL_ETCH;
+    if (!etch) { int rc = stencil_prepare_deposit(g); if (rc) return rc; }
+    const Pending p = g->pend;
+    const uint8_t* halo_lo = p.has_lower ? g->halo[2] : nullptr;           // not read by interior tiles; they tell the bands
+    const uint8_t* halo_up = p.has_upper ? g->halo[3] : nullptr;
+    int rc = launch_stencil(g, etch, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, etch ? -1 : p.P, PART_INTERIOR);
+    if (rc) return rc;
+    g->pend.interior_done = true;
+    return CG_OK;
+}
+
 int cg_stencil_finish(cg_grid* g) {
     NEED(g);
     if (!g->pend.active) return fail(g, CG_ERR_STATE, "no stencil step is open");
+    const bool etch = g->pend.kind == CG_STENCIL_ETCH;
+    if (!etch && !g->pend.interior_done) { int rc = stencil_prepare_deposit(g); if (rc) { g->pend.active = false; return rc; } }
     Pending p = g->pend;
     g->pend.active = false;
     bool ok; const uint8_t* mask = mask_ptr(g, p.mask_id, &ok);
     if (!ok) return fail(g, CG_ERR_ARG, "mask %d vanished during the step", p.mask_id);
-    const bool etch = p.kind == CG_STENCIL_ETCH;
     const uint8_t* halo_lo = p.has_lower ? g->halo[2] : nullptr;
     const uint8_t* halo_up = p.has_upper ? g->halo[3] : nullptr;
+    const int part = p.interior_done ? PART_BOUNDARY : PART_ALL;
     if (etch) {
-        int rc = launch_stencil(g, true, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, -1); if (rc) return rc;
+        int rc = launch_stencil(g, true, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, -1, part); if (rc) return rc;
         std::swap(g->top, g->top_alt);
         return CG_OK;
     }
 
-    bool may_overflow = g->len_bound >= g->lmax;
-    if (may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; may_overflow = g->len_bound >= g->lmax; }
-    if (may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
-    int P = 0;
-    int rc = take_append_plane(g, &P); if (rc) return rc;
-    rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, P); if (rc) return rc;
-    if (may_overflow) {
+    int rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, p.P, part); if (rc) return rc;
+    if (p.may_overflow) {
         int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
         if (fl[0]) {
             const int oldL = g->lmax;
             rc = grow_planes(g); if (rc) return rc;
-            rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, oldL, halo_lo, halo_up, P); if (rc) return rc;
+            rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, oldL, halo_lo, halo_up, p.P); if (rc) return rc;
         }
     }
     std::swap(g->top, g->top_alt);

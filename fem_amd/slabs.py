@@ -5,7 +5,8 @@ are independent except for the lateral stencil of conformal deposition / isotrop
 radius R reaches into the neighbouring slabs.  For those steps each rank
   1. packs the top heights (+ etchable flags) of its R boundary rows   grid.stencil_begin
   2. swaps R boundary rows with its two neighbours          torch.distributed send/recv (RCCL)
-  3. runs the dilation / erosion and the column update      grid.stencil_finish
+     while the rows that reach no neighbour are updated     grid.stencil_interior
+  3. runs the dilation / erosion and the column update      grid.stencil_finish (the rows left)
 Layer stacks never move between GPUs.  Whole-domain scalars (max height, checksum, CMP's
 target height, "is there any gap") are all-reduced.  strip_connected / identify_cavity flood
 across slab edges: each rank relaxes to its local fixpoint, swaps one boundary row (whole
@@ -30,16 +31,23 @@ class TorchComm:
     def __init__(self, rank, world, device, group=None):
         self.rank, self.world, self.device, self.group = rank, world, device, group
 
-    def swap(self, send_lower, send_upper, recv_lower, recv_upper):
-        """send_lower -> rank-1 (arrives as its recv_upper), send_upper -> rank+1 (its recv_lower)."""
+    def start_swap(self, send_lower, send_upper, recv_lower, recv_upper):
+        """send_lower -> rank-1 (arrives as its recv_upper), send_upper -> rank+1 (its recv_lower).
+        Returns what finish_swap waits for; with nccl the transfers run on RCCL's own stream, after
+        the work already queued on the current one."""
         ops = []
         if self.rank > 0:
             ops += [dist.P2POp(dist.isend, send_lower, self.rank - 1, self.group), dist.P2POp(dist.irecv, recv_lower, self.rank - 1, self.group)]
         if self.rank < self.world - 1:
             ops += [dist.P2POp(dist.isend, send_upper, self.rank + 1, self.group), dist.P2POp(dist.irecv, recv_upper, self.rank + 1, self.group)]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def finish_swap(self, reqs):
+        for req in reqs:
+            req.wait()
+
+    def swap(self, send_lower, send_upper, recv_lower, recv_upper):
+        self.finish_swap(self.start_swap(send_lower, send_upper, recv_lower, recv_upper))
 
     def reduce(self, values, op="max", dtype=torch.int64):
         t = torch.tensor(list(values), dtype=dtype, device=self.device)
@@ -75,8 +83,15 @@ class SlabGrid:
         return int(math.ceil(t / self.dx))
 
     def _exchange(self, R):
+        """Swap the R halo rows; the rows that need none of them are computed while they travel."""
         n = R * self.ny * 3
-        self.comm.swap(*[t[:n] for t in self._halo])
+        bufs = [t[:n] for t in self._halo]
+        interior = getattr(self.grid, "stencil_interior", None)
+        if interior is None or not hasattr(self.comm, "start_swap"):
+            return self.comm.swap(*bufs)
+        reqs = self.comm.start_swap(*bufs)
+        interior()
+        self.comm.finish_swap(reqs)
 
     def _step(self, kind, mask, mat, t, S):
         if self.world > 1:

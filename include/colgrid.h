@@ -244,7 +244,11 @@ int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q);
  *                        (i-1) and upper (i+1) neighbour, each R*ny*3 bytes
  *                        (u16 top height rows followed by u8 etchable-flag rows);
  *   (caller moves the bytes, e.g. with RCCL send/recv on the handle's stream)
- *   cg_stencil_finish -> dilation / erosion and the per-column update.
+ *   cg_stencil_interior (optional, while the bytes are in flight) -> the same update for
+ *                        the tile rows whose stencil stays inside the slab; they read no
+ *                        halo message, so the exchange overlaps with them;
+ *   cg_stencil_finish -> dilation / erosion and the per-column update (of the rows
+ *                        cg_stencil_interior has not done).
  * has_lower / has_upper = 0 means domain edge: heights are clamp-replicated and flags are
  * zero there (cg1:373-387, 671).
  */
@@ -252,6 +256,7 @@ int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q);
 #define CG_STENCIL_ETCH    1
 int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thickness,
                      double conformality, int has_lower, int has_upper, int* radius_rows);
+int cg_stencil_interior(cg_grid* g);
 int cg_halo_buffers(cg_grid* g, void** send_lower, void** send_upper,
                     void** recv_lower, void** recv_upper, size_t* bytes_each);
 int cg_stencil_finish(cg_grid* g);
