@@ -913,6 +913,7 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     const double latRange = t * S;
     { int rcs = ensure_split(g); if (rcs) return rcs; }
     stats_begin(g);
+    if (kind == CG_STENCIL_DEPOSIT && mat == CG_MAT_CAVITY) g->has_cavity = true;      // a "cavity" laid down as a film
     if (latRange < std::min(g->dx, g->dy)) {                              // cg1:445, 609
         if (kind == CG_STENCIL_DEPOSIT) return run_depo_vertical(g, mask, mat, t);
         const dim3 grid(blocks_for(g->N)), blk(256);

@@ -65,6 +65,7 @@ class SlabGrid:
         self.has_lower, self.has_upper = rank > 0, rank < world - 1
         self._halo = None
         self._rows = 0
+        self._gaps_anywhere = None      # "some slab may hold a gap or a cavity": None = ask the ranks again
         if world > 1:
             self._alloc_halo(halo_rows)
 
@@ -114,15 +115,22 @@ class SlabGrid:
 
     # ---- the reference's step names
     def deposit_general(self, mask, matId, thickness, conformality=1.0):
+        if matId == 2:
+            self._gaps_anywhere = None                   # material 2 is what identify_cavity strips
         self._step(STENCIL_DEPOSIT, mask, matId, thickness, conformality)
         if self.world > 1 and self._radius(thickness, conformality) > 0:
             self.identify_cavity()                       # script_columngrid.js:543; a slab handle leaves it to us
+
+    def invalidate(self):
+        """Call after changing the handle behind this driver's back (upload, snapshot load ...)."""
+        self._gaps_anywhere = None
 
     def strip_connected(self, matId):
         """strip_connected(matId) (script_columngrid.js:867 - script_columngrid2.js:1) over all slabs."""
         if self.world == 1:
             return self.grid.strip_connected(matId)
         g = self.grid
+        self._gaps_anywhere = None
         planes = self._reduce_max([g.cavity_state()[2]])[0]
         nbytes = g.ghost_bytes(planes)
         if getattr(self, "_ghost", None) is None or self._ghost[0].numel() < nbytes:
@@ -143,14 +151,19 @@ class SlabGrid:
         """identify_cavity() (script_columngrid2.js:9-83) over all slabs."""
         if self.world == 1:
             return self.grid.identify_cavity()
-        gaps, cav, _, _ = self.grid.cavity_state(flags_only=True)
-        if not self._reduce_max([1 if (gaps or cav) else 0])[0]:
+        # the flags only change in strip / CMP / cavity passes (all of them collective calls of this
+        # class), so the answer of the last all-reduce stands until one of those has run
+        if self._gaps_anywhere is None:
+            gaps, cav, _, _ = self.grid.cavity_state(flags_only=True)
+            self._gaps_anywhere = bool(self._reduce_max([1 if (gaps or cav) else 0])[0])
+        if not self._gaps_anywhere:
             return
         top_q = self._reduce_max([self.grid.cavity_state()[3]])[0]
         zs = self.grid.zScale
         hmax_q = top_q if top_q > 0 else int(math.floor(1.0 / zs + 0.5)) & 0xFFFF      # maxHeight() is 1 on an empty grid
         self.grid.cavity_fill(hmax_q)
         self.strip_connected(2)
+        self._gaps_anywhere = None
 
     def cmp(self, depth, stopMatId=0):
         """cmp(depth, stopMatId) (script_columngrid.js:747-859) over all slabs."""
@@ -163,6 +176,7 @@ class SlabGrid:
         z_top = top_q * zs
         target = z_top - depth if (stopMatId == 0 or not found) else max(z_top - depth, stop_q * zs)
         self.grid.cmp_apply(target, stopMatId)
+        self._gaps_anywhere = None
         self.identify_cavity()
 
     def etch_general(self, mask, matId, thickness, conformality=1.0):
@@ -170,6 +184,7 @@ class SlabGrid:
 
     def createNewGrid(self):
         self.grid.createNewGrid()
+        self._gaps_anywhere = False      # an empty grid has neither
 
     # ---- whole-domain scalars
     def maxHeight(self):

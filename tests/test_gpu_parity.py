@@ -368,6 +368,27 @@ def test_lmax_follows_the_reference_while_columns_have_gaps():
     g.close()
 
 
+def test_material_2_laid_down_as_a_film():
+    """Material id 2 is what identify_cavity strips: a flow that deposits it like any film must take
+    the full cavity pass after conformal deposits, not the no-gap shortcut."""
+    fem = _engine()
+    nx, ny = 64, 48
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    half = np.zeros((nx, ny), np.uint8); half[:, :20] = 1
+    pit = np.zeros((nx, ny), np.uint8); pit[24:40, 10:30] = 1
+    gm = {"half": g.mask_from_raster(half.reshape(-1)), "pit": g.mask_from_raster(pit.reshape(-1))}
+    om = {"half": half.reshape(-1), "pit": pit.reshape(-1)}
+    for k, (kind, m, mat, t, S) in enumerate([("d", None, 3, 10, 0), ("d", "half", 2, 3, 0), ("d", None, 4, 4, 1.0), ("e", "pit", 255, 6, 0),
+                                              ("d", None, 5, 2, 1.0), ("d", "pit", 2, 2, 0.9), ("e", None, 5, 3, 1.0), ("d", None, 6, 3, 1.0)]):
+        for grid, masks in ((g, gm), (o, om)):
+            fn = grid.deposit_general if kind == "d" else grid.etch_general
+            fn(masks[m] if m else None, mat, t, S)
+        assert g.checksum() == o.checksum(), f"step {k}"
+    _assert_same(g, o.arrays(), "final")
+    g.close()
+
+
 def test_many_deposit_steps_recycle_planes():
     """Every depositing launch takes a plane of its own; with 32 planes and 90 deposits on short
     columns the engine has to compact the columns several times.  Oracle equality after every step,
