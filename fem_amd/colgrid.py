@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcolgrid.so")
+LIB_PATH = os.environ.get("COLGRID_LIB") or os.path.join(_HERE, "lib", "libcolgrid.so")      # the override is for A/B timing of two builds
 
 CG_MASK_NONE = -1
 CG_NSTAT = 8

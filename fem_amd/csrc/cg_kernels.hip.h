@@ -14,9 +14,9 @@
 //                what the kernels that restructure whole columns work on (strip, cavity, CMP,
 //                wet etch, ALD, upload).
 //
-//   split form   len[c] u8, top[c] u32 = the top interval (0: empty column), topz0[c] u16 = its
-//                bottom, link[c] u8 = the plane holding the interval below it, and for an interval
-//                stored in plane p: rec[p*N + c], prv[p*N + c] u8 = the plane of the one below.
+//   split form   len[c] u8, top[c] u32 = the top interval (0: empty column), link[c] u8 = the
+//                plane holding the interval below it (whose z1 is the top's bottom), and for an
+//                interval stored in plane p: rec[p*N + c], prv[p*N + c] u8 = the plane of the one below.
 //                What the vertical and lateral steps work on: they only ever look at the top, so
 //                extend / partial etch / "material differs" touch streams whose addresses do not
 //                depend on the column length.  An append pushes the old top into the plane P of
@@ -46,7 +46,6 @@ struct GridView {
     uint32_t* rec;
     uint32_t* top;      // split form: the top interval of every column (0 for an empty column)
     uint32_t* top_w;    // where updated tops are stored: top itself, or the other buffer in a lateral step
-    uint16_t* topz0;    // split form: its bottom height
     uint8_t*  link;     // split form: plane that holds the interval below the top (len >= 2)
     uint8_t*  prv;      // split form: prv[p*N + c] = plane of the interval below the one stored in plane p
     int       P;        // split form: the plane this launch pushes old tops into (-1: it cannot append)
@@ -55,7 +54,9 @@ struct GridView {
     int       nx, ny;
     int       lmax;     // planes provisioned
     int       i0;       // global row of local row 0
-    int       tile_i0;  // lateral steps: tile row of block 0 (a launch may cover a band of tile rows)
+    int       tile_i0;  // lateral steps: first tile row of this launch (a launch may cover a band of tile rows)
+    int       tile_in;  // lateral steps: tile rows of this launch
+    int       sup_i, sup_j;   // lateral steps: tiles per super-tile (see tile_of_block)
     double    zs;       // nm per step
     double    inv_zs;   // 1/zs, rounded once on the host
 };
@@ -107,7 +108,7 @@ __device__ __forceinline__ uint16_t quantz(double z, double zs, double inv_zs) {
 // per-column update primitives (scalar forms; the vector forms below do the same per lane)
 // ------------------------------------------------------------------------------------------
 // All of them work on the split form of a column (GridView::split): the top interval in
-// top[c] / topz0[c], intervals 0 .. len-2 in the planes.
+// top[c], intervals 0 .. len-2 in the planes.
 
 // All l intervals of a column bottom-up into out[], whichever form the grid is in (read-only kernels).
 __device__ __forceinline__ void load_column(const GridView& g, size_t c, int l, uint32_t* out) {
@@ -156,7 +157,6 @@ __device__ __forceinline__ int depo_at_top(const GridView& g, size_t c, int l, i
         g.link[c] = (uint8_t)g.P;
     }
     g.top_w[c] = rec_make(q, matId);                           // another material below: RUN stays clear
-    g.topz0[c] = (uint16_t)topq;
     g.len[c] = (uint8_t)(l + 1);
     return 2;
 }
@@ -182,14 +182,15 @@ __device__ __forceinline__ int apply_etch_at(const GridView& g, size_t c, int l,
     double remaining = dz;
     int removed = 0; bool touched = false;
     const int l0 = l;
-    uint32_t r = g.top[c]; unsigned z0q = g.topz0[c];
+    uint32_t r = g.top[c];
     int lk = l > 1 ? g.link[c] : 0;
+    unsigned z0q = l > 1 ? rec_z1(g.rec[(size_t)lk * g.N + c]) : 0u;
     while (etch_round(g, r, z0q, l, remaining, matId, isAll, touched, removed)) {
         if (l > 0) reload_top(g, c, l, r, z0q, lk); else { r = 0; z0q = 0; }
     }
     if (touched) {
         g.top_w[c] = r;
-        if (l != l0) { g.topz0[c] = (uint16_t)z0q; g.len[c] = (uint8_t)l; g.link[c] = (uint8_t)lk; }
+        if (l != l0) { g.len[c] = (uint8_t)l; g.link[c] = (uint8_t)lk; }
     }
     return (touched ? 0x10000 : 0) | removed;
 }
@@ -314,24 +315,21 @@ __device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsign
         // the old tops go into this step's plane (whatever the column lengths: one dense line per
         // 32 columns), each with the link to what was below it
         const size_t b = (size_t)g.P * g.N + c0;
-        u16x4 z; u8x4 nk = lk;
+        u8x4 nk = lk;
         if (app == 15u) {
             if (as_u32(ln) != 0u) {                            // (columns that were empty push nothing)
                 st_rec4(g.rec + b, tv);
                 st_u8x4(g.prv + b, lk);
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) { z[j] = (unsigned short)rec_z1(ln[j] ? tv[j] : 0); if (ln[j]) nk[j] = (uint8_t)g.P; }
+            for (int j = 0; j < 4; j++) if (ln[j]) nk[j] = (uint8_t)g.P;
         } else {
-            z = ld_u16x4(g.topz0 + c0);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (!((app >> j) & 1)) continue;
-                z[j] = (unsigned short)rec_z1(ln[j] ? tv[j] : 0);
                 if (ln[j]) { g.rec[b + j] = tv[j]; g.prv[b + j] = lk[j]; nk[j] = (uint8_t)g.P; }
             }
         }
-        st_u16x4(g.topz0 + c0, z);
         st_u8x4(g.len + c0, nl);
         st_u8x4(g.link + c0, nk);
         if (STATS) n_app += __popc(app);
@@ -341,72 +339,84 @@ __device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsign
     return true;
 }
 
+// The intervals below the tops of the columns in `want` (only those with l > 1 have one): their
+// records b[] -- the top's bottom is rec_z1(b), and b is the new top should the whole top layer
+// go -- and their links pv[] (loaded along with the records: fetching them only once a layer is
+// known to go costs a round trip more per removed layer, measured 10 % on such steps).  Columns
+// whose links name the same plane (they were pushed by the same step) share the vector loads.
+__device__ __forceinline__ void load_below4(const GridView& g, size_t c0, unsigned want, const int (&l)[4], const int (&lk)[4],
+                                            uint32_t (&b)[4], int (&pv)[4]) {
+    unsigned todo = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (((want >> j) & 1) && l[j] > 1) todo |= 1u << j;
+    while (todo) {
+        const int j0 = __ffs(todo) - 1;
+        const int p = lk[j0];
+        unsigned sel = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (((todo >> j) & 1) && lk[j] == p) sel |= 1u << j;
+        todo &= ~sel;
+        const size_t at = (size_t)p * g.N + c0;
+        if (sel & (sel - 1)) {
+            const u32x4 A = ld_rec4(g.rec + at);
+            const u8x4 PV = ld_u8x4(g.prv + at);
+#pragma unroll
+            for (int j = 0; j < 4; j++) if ((sel >> j) & 1) { b[j] = A[j]; pv[j] = PV[j]; }
+        } else {
+            b[j0] = g.rec[at + j0]; pv[j0] = g.prv[at + j0];
+        }
+    }
+}
+
 // _applyEtchAt on the open columns of a group: column j loses dz[j] (> 0) from the top.
-// tv / zv / lkv = the 4 tops, their bottoms and their links.  A column that loses its whole top
-// layer reloads the next one through its link; columns whose links name the same plane (they were
-// pushed by the same step) share the vector loads.
+// tv / lkv = the 4 tops and their links; `have` names the columns whose interval below the top
+// the caller has loaded already (b0 / pv0, see load_below4).  A column that loses its whole top
+// layer continues with the interval below it.
 template <bool STATS>
 __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
-                                            bool isAll, u32x4 tv, u16x4 zv, u8x4 lkv, unsigned& n_touched, unsigned& n_removed) {
+                                            bool isAll, u32x4 tv, u8x4 lkv, unsigned have, const uint32_t (&b0)[4], const int (&pv0)[4],
+                                            unsigned& n_touched, unsigned& n_removed) {
     int l[4] = {ln[0], ln[1], ln[2], ln[3]};
     int lk[4] = {lkv[0], lkv[1], lkv[2], lkv[3]};
     uint32_t r[4] = {tv[0], tv[1], tv[2], tv[3]};
-    unsigned z0[4] = {zv[0], zv[1], zv[2], zv[3]};
     double rem[4] = {dz[0], dz[1], dz[2], dz[3]};
-    unsigned need = 0, dirty = 0, popped = 0;
+    uint32_t b[4] = {b0[0], b0[1], b0[2], b0[3]};
+    int pv[4] = {pv0[0], pv0[1], pv0[2], pv0[3]};
+    unsigned dirty = 0, popped = 0, act = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (!((open >> j) & 1) || l[j] <= 0) continue;
-        bool t = false; int rm = 0;
-        if (etch_round(g, r[j], z0[j], l[j], rem[j], matId, isAll, t, rm)) { popped |= 1u << j; if (l[j] > 0) need |= 1u << j; else { r[j] = 0; z0[j] = 0; } }
-        if (t) dirty |= 1u << j;
-        if (STATS) n_removed += rm;
-    }
-    while (need) {
-        const int j0 = __ffs(need) - 1;
-        const int p = lk[j0];                                  // plane of the new tops of this pass
-        unsigned sel = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) if (((need >> j) & 1) && lk[j] == p) sel |= 1u << j;
-        need &= ~sel;
-        const u32x4 A = ld_rec4(g.rec + (size_t)p * g.N + c0);
-        const u8x4 PV = ld_u8x4(g.prv + (size_t)p * g.N + c0);
-        // the intervals below the new tops (for their bottoms): one vector load when they share a plane
-        int p2 = -1; bool same = true;
-#pragma unroll
-        for (int j = 0; j < 4; j++) if (((sel >> j) & 1) && l[j] > 1) { if (p2 < 0) p2 = PV[j]; else if (PV[j] != p2) same = false; }
-        u32x4 B = (u32x4)(0);
-        if (p2 >= 0 && same) B = ld_rec4(g.rec + (size_t)p2 * g.N + c0);
+    for (int j = 0; j < 4; j++)
+        if (((open >> j) & 1) && l[j] > 0 && rem[j] > CG_EPS && (isAll || rec_mat(r[j]) == matId)) act |= 1u << j;   // cg1:565-569
+    while (act) {
+        load_below4(g, c0, act & ~have, l, lk, b, pv);
+        have = 0;
+        unsigned next = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (!((sel >> j) & 1)) continue;
-            r[j] = A[j];
-            int q2 = PV[j];
-            uint32_t b = 0;
-            if (l[j] > 1) b = same ? B[j] : g.rec[(size_t)q2 * g.N + c0 + j];
+            if (!((act >> j) & 1)) continue;
+            const uint32_t below = l[j] > 1 ? b[j] : 0u;
+            const double z1 = (double)rec_z1(r[j]) * g.zs, z0 = (double)rec_z1(below) * g.zs, thick = z1 - z0;
+            dirty |= 1u << j;
+            if (rem[j] < thick - CG_EPS) { r[j] = rec_with_z1(r[j], quantz(z1 - rem[j], g.zs, g.inv_zs)); rem[j] = 0; continue; }   // cg1:574-578
+            rem[j] -= thick; l[j] -= 1; popped |= 1u << j;                                                                          // cg1:579-587
+            if (STATS) n_removed += 1;
+            if (l[j] == 0) { r[j] = 0; lk[j] = 0; continue; }
+            r[j] = below; lk[j] = l[j] > 1 ? pv[j] : 0;
             if (rec_hole(r[j])) {                              // a gap under the removed layer goes with it
                 l[j] -= 1;
-                if (l[j] > 0) {
-                    r[j] = b;
-                    const int q3 = l[j] > 1 ? g.prv[(size_t)q2 * g.N + c0 + j] : 0;
-                    b = l[j] > 1 ? g.rec[(size_t)q3 * g.N + c0 + j] : 0;
-                    q2 = q3;
-                } else { r[j] = 0; b = 0; }
+                if (l[j] == 0) { r[j] = 0; lk[j] = 0; continue; }
+                const size_t at = (size_t)lk[j] * g.N + c0 + j;
+                r[j] = g.rec[at]; lk[j] = l[j] > 1 ? g.prv[at] : 0;
             }
-            z0[j] = rec_z1(b); lk[j] = q2;
-            bool t = false; int rm = 0;
-            if (etch_round(g, r[j], z0[j], l[j], rem[j], matId, isAll, t, rm)) { if (l[j] > 0) need |= 1u << j; else { r[j] = 0; z0[j] = 0; } }
-            if (STATS) n_removed += rm;
+            if (rem[j] > CG_EPS && (isAll || rec_mat(r[j]) == matId)) next |= 1u << j;
         }
+        act = next;
     }
     if (dirty) {
         u32x4 nv; nv[0] = r[0]; nv[1] = r[1]; nv[2] = r[2]; nv[3] = r[3];
         st_rec4(g.top_w + c0, nv);
         if (popped) {
-            u16x4 nz; nz[0] = (unsigned short)z0[0]; nz[1] = (unsigned short)z0[1]; nz[2] = (unsigned short)z0[2]; nz[3] = (unsigned short)z0[3];
             u8x4 nl; nl[0] = (uint8_t)l[0]; nl[1] = (uint8_t)l[1]; nl[2] = (uint8_t)l[2]; nl[3] = (uint8_t)l[3];
             u8x4 nk; nk[0] = (uint8_t)lk[0]; nk[1] = (uint8_t)lk[1]; nk[2] = (uint8_t)lk[2]; nk[3] = (uint8_t)lk[3];
-            st_u16x4(g.topz0 + c0, nz);
             st_u8x4(g.len + c0, nl);
             st_u8x4(g.link + c0, nk);
         }
@@ -437,11 +447,11 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
         if (tile >= ntiles) continue;
         if (row_tiles > 1) { const size_t r = tile / row_tiles, q = tile - r * row_tiles; tile = r * row_tiles + (q + r) % row_tiles; }
         const size_t gbase = tile * tile_groups + threadIdx.x;
-        u8x4 ln[U], lk[U]; unsigned open[U]; u32x4 tv[U]; u16x4 zv[U];
+        u8x4 ln[U], lk[U]; unsigned open[U]; u32x4 tv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t gi = gbase + (size_t)u * 256;
-            open[u] = 0; ln[u] = splat4(0); lk[u] = splat4(0); tv[u] = (u32x4)(0); zv[u] = (u16x4)(0);
+            open[u] = 0; ln[u] = splat4(0); lk[u] = splat4(0); tv[u] = (u32x4)(0);
             if (gi < ngroups) {
                 const size_t c0 = gi << 2;
                 open[u] = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
@@ -449,7 +459,6 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
                     ln[u] = ld_u8x4(g.len + c0);
                     lk[u] = ld_u8x4(g.link + c0);
                     tv[u] = ld_rec4(g.top + c0);
-                    if (ETCH) zv[u] = ld_u16x4(g.topz0 + c0);
                 }
             }
         }
@@ -458,7 +467,8 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
             if (!open[u]) continue;
             const size_t c0 = (gbase + (size_t)u * 256) << 2;
             if (STATS) loc[0] += __popc(open[u]);
-            if (ETCH) etch_group4<STATS>(g, c0, open[u], ln[u], dz, matId, isAll, tv[u], zv[u], lk[u], loc[1], loc[2]);
+            if (ETCH) { const uint32_t nb[4] = {0, 0, 0, 0}; const int np[4] = {0, 0, 0, 0};
+                        etch_group4<STATS>(g, c0, open[u], ln[u], dz, matId, isAll, tv[u], lk[u], 0u, nb, np, loc[1], loc[2]); }
             else depo_group4<STATS>(g, c0, open[u], ln[u], dz, matId, tv[u], lk[u], flags, loc[1], loc[2]);
         }
     }
@@ -481,6 +491,25 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
 //
 // Message of Rh rows: Rh*ny u16 heights, then Rh*ny u8 flags (zeros for deposit).
 // send_lower = rows 0..Rh-1, send_upper = rows nx-Rh..nx-1.
+// Workgroup b runs on XCD b mod 8, each XCD has its own L2, and neighbouring tiles share halo
+// rows and columns (and the 128-B lines that straddle a tile edge).  Blocks that follow each other
+// on ONE XCD (b, b+8, b+16, ...) therefore get the sup_i x sup_j tiles of one super-tile, so the
+// shared lines are fetched from HBM once; super-tiles go round the XCDs, rotated by their row so
+// that a mask open in some column ranges only does not load the XCDs unevenly.
+// Blocks beyond the last super-tile or tile return false.
+__device__ __forceinline__ bool tile_of_block(const GridView& g, int tiles_j, int& tile_i, int& tile_j) {
+    const int per = g.sup_i * g.sup_j;
+    const int b = blockIdx.x, x = b & 7, q = b >> 3;
+    const int n_sj = (tiles_j + g.sup_j - 1) / g.sup_j, n_si = (g.tile_in + g.sup_i - 1) / g.sup_i;
+    const int s = (q / per) * 8 + x, within = q % per;
+    if (s >= n_sj * n_si) return false;
+    const int s_i = s / n_sj, s_j = (s - s_i * n_sj + s_i) % n_sj;
+    const int ti = s_i * g.sup_i + within / g.sup_j, tj = s_j * g.sup_j + within % g.sup_j;
+    if (ti >= g.tile_in || tj >= tiles_j) return false;
+    tile_i = g.tile_i0 + ti; tile_j = tj;
+    return true;
+}
+
 __device__ __forceinline__ bool etchable(uint32_t r, int matId, bool isAll) { return r != 0 && (isAll || rec_mat(r) == matId); }
 
 __global__ __launch_bounds__(256) void k_halo_pack(GridView g, const uint8_t* __restrict__ mask, int matId, int etch, int Rh,
@@ -538,8 +567,8 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
     const int pitch = TJ + 2 * R;
     const int tile_rows = TI + 2 * R;
     const int tiles_j = (g.ny + TJ - 1) / TJ;
-    const int bi = blockIdx.x / tiles_j;
-    const int tile_i = g.tile_i0 + bi, tile_j = (blockIdx.x - bi * tiles_j + tile_i) % tiles_j;
+    int tile_i, tile_j;
+    if (!tile_of_block(g, tiles_j, tile_i, tile_j)) return;
     const int i_base = tile_i * TI, j_base = tile_j * TJ;
 
     // ---- stage heights (as float32 of q*zscale, cg1:465) with halo; flags fold into +inf
@@ -632,7 +661,10 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 int l = g.len[c];
                 if (ETCH) {
                     float F = 0.f;
-                    if (!isAll && l > 0) F = (float)fmax(0.0, floor_of_top_run(g, c, l, matId, g.top[c], g.topz0[c], loc[3]));
+                    if (!isAll && l > 0) {
+                        const unsigned z0q = l > 1 ? rec_z1(g.rec[(size_t)g.link[c] * g.N + c]) : 0u;
+                        F = (float)fmax(0.0, floor_of_top_run(g, c, l, matId, g.top[c], z0q, loc[3]));
+                    }
                     float hp = fmaxf(0.f, fmaxf(F, m[r]));             // cg1:725
                     double dz = (double)own[r] - (double)hp;
                     if (dz > CG_EPS) {
@@ -695,10 +727,8 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
     constexpr int Rp = G::Rp, PITCH = G::PITCH, ROWS = G::ROWS, W = G::W, GPR = G::GPR, TIS = G::TIS, GX = G::GX;
     __shared__ __align__(16) float s_h[ROWS * PITCH];
     const int tiles_j = (g.ny + TJS - 1) / TJS;
-    // rotate the column tile by the row tile so that one XCD (blockIdx mod 8) does not always get
-    // the same column range (see k_vertical_g4)
-    const int bi = blockIdx.x / tiles_j;
-    const int tile_i = g.tile_i0 + bi, tile_j = (blockIdx.x - bi * tiles_j + tile_i) % tiles_j;
+    int tile_i, tile_j;
+    if (!tile_of_block(g, tiles_j, tile_i, tile_j)) return;
     const int i_base = tile_i * TIS, j_base = tile_j * TJS;
     const float INF = __builtin_inff();
 
@@ -840,18 +870,23 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                 }
                 if (open) stored = depo_group4<STATS>(g, c0, open, ln, dz, matId, tv, lkv, flags, loc[1], loc[2]);
             } else {
-                const u16x4 zv = ld_u16x4(g.topz0 + c0);
+                // every etchable column needs the bottom of its top layer: for the floor (when a
+                // material is named) and for the cut itself
+                const int l4[4] = {ln[0], ln[1], ln[2], ln[3]};
+                const int k4[4] = {lkv[0], lkv[1], lkv[2], lkv[3]};
+                uint32_t b4[4] = {0, 0, 0, 0}; int p4[4] = {0, 0, 0, 0};
+                load_below4(g, c0, act, l4, k4, b4, p4);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     if (!((act >> c) & 1)) continue;
                     // floor = bottom of the top run of matId (cg1:646-660)
                     float F = 0.f;
-                    if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, ln[c], matId, tv[c], zv[c], loc[3]));
+                    if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, ln[c], matId, tv[c], l4[c] > 1 ? rec_z1(b4[c]) : 0u, loc[3]));
                     const float hpv = fmaxf(0.f, fmaxf(F, m[c]));                     // cg1:725
                     const double d = (double)own[c] - (double)hpv;
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) stored = etch_group4<STATS>(g, c0, open, ln, dz, matId, isAll, tv, zv, lkv, loc[1], loc[2]);
+                if (open) stored = etch_group4<STATS>(g, c0, open, ln, dz, matId, isAll, tv, lkv, act, b4, p4, loc[1], loc[2]);
             }
         }
         if (!stored && g.top_w != g.top) st_rec4(g.top_w + c0, tv);       // columns that stay as they are
@@ -1319,17 +1354,16 @@ __global__ __launch_bounds__(256) void k_demote(GridView g) {
     }
 }
 
-// whole -> split: top / topz0 / link from the planes (interval k stays in plane k, chained to
+// whole -> split: top / link from the planes (interval k stays in plane k, chained to
 // plane k-1), and the RUN flag of every interval brought up to date (the kernels that
 // restructure columns do not maintain it)
 __global__ __launch_bounds__(256) void k_promote(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
-        int below_mat = -1; unsigned prev = 0, z0 = 0; uint32_t r = 0;
+        int below_mat = -1; uint32_t r = 0;
         for (int k = 0; k < l; k++) {
             r = g.rec[(size_t)k * g.N + c];
-            z0 = prev; prev = rec_z1(r);
             if (k > 0 && k < l - 1) g.prv[(size_t)k * g.N + c] = (uint8_t)(k - 1);
             if (rec_hole(r)) continue;
             const uint32_t want = (r & ~REC_RUN) | ((below_mat == rec_mat(r)) ? REC_RUN : 0u);
@@ -1337,7 +1371,6 @@ __global__ __launch_bounds__(256) void k_promote(GridView g) {
             below_mat = rec_mat(r);
         }
         g.top[c] = l > 0 ? r : 0;
-        g.topz0[c] = (uint16_t)(l > 0 ? z0 : 0);
         g.link[c] = (uint8_t)(l > 1 ? l - 2 : 0);
     }
 }

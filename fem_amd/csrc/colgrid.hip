@@ -55,7 +55,7 @@ struct ConfKernel {
 };
 
 struct Snapshot {
-    uint8_t* len = nullptr; uint32_t* rec = nullptr; uint32_t* top = nullptr; uint16_t* topz0 = nullptr;
+    uint8_t* len = nullptr; uint32_t* rec = nullptr; uint32_t* top = nullptr;
     uint8_t* link = nullptr; uint8_t* prv = nullptr; int nextp = 0;
     bool split = true;
     int lmax = 0; int lmax_vis = 0; int len_bound = 0; bool has_gaps = false, has_cavity = false;
@@ -80,7 +80,7 @@ struct cg_grid {
     int lmax = 32;                                        // planes allocated
     int lmax_vis = 32;                                    // the Lmax the reference would have now (stride of host-side arrays)
     uint8_t* len = nullptr; uint32_t* rec = nullptr;      // see cg_kernels.hip.h for the layout
-    uint32_t* top = nullptr; uint16_t* topz0 = nullptr;   // split form: top interval of every column and its bottom
+    uint32_t* top = nullptr;                              // split form: top interval of every column
     uint32_t* top_alt = nullptr;                          // the buffer a lateral step writes its new tops to (then swapped)
     uint8_t* link = nullptr; uint8_t* prv = nullptr;      // split form: chain of a column's intervals through the planes
     int nextp = 0;                                        // split form: first plane no interval lives in yet
@@ -174,9 +174,9 @@ int js_to_int32(double v) {                  // (v | 0)
 
 GridView view(const cg_grid* g) {
     GridView v;
-    v.len = g->len; v.rec = g->rec; v.top = g->top; v.top_w = g->top; v.topz0 = g->topz0; v.split = g->split ? 1 : 0;
+    v.len = g->len; v.rec = g->rec; v.top = g->top; v.top_w = g->top; v.split = g->split ? 1 : 0;
     v.link = g->link; v.prv = g->prv; v.P = -1;
-    v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.tile_i0 = 0; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
+    v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.tile_i0 = 0; v.tile_in = 0; v.sup_i = 1; v.sup_j = 1; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
     return v;
 }
 
@@ -189,11 +189,10 @@ void free_planes(cg_grid* g) {
     if (g->len) (void)hipFree(g->len);
     if (g->rec) (void)hipFree(g->rec);
     if (g->top) (void)hipFree(g->top);
-    if (g->topz0) (void)hipFree(g->topz0);
     if (g->top_alt) (void)hipFree(g->top_alt);
     if (g->link) (void)hipFree(g->link);
     if (g->prv) (void)hipFree(g->prv);
-    g->len = nullptr; g->rec = nullptr; g->top = nullptr; g->topz0 = nullptr; g->top_alt = nullptr; g->link = nullptr; g->prv = nullptr;
+    g->len = nullptr; g->rec = nullptr; g->top = nullptr; g->top_alt = nullptr; g->link = nullptr; g->prv = nullptr;
 }
 
 int alloc_planes(cg_grid* g, int lmax) {
@@ -202,7 +201,6 @@ int alloc_planes(cg_grid* g, int lmax) {
     HIPCHK(g, hipMalloc(&g->len, std::max<size_t>(g->N, 4)));
     HIPCHK(g, hipMalloc(&g->rec, std::max<size_t>(4 * S, 4)));
     HIPCHK(g, hipMalloc(&g->top, std::max<size_t>(4 * g->N, 16)));
-    HIPCHK(g, hipMalloc(&g->topz0, std::max<size_t>(2 * g->N, 16)));
     HIPCHK(g, hipMalloc(&g->top_alt, std::max<size_t>(4 * g->N, 16)));
     HIPCHK(g, hipMalloc(&g->link, std::max<size_t>(g->N, 16)));
     HIPCHK(g, hipMalloc(&g->prv, std::max<size_t>(S, 16)));
@@ -210,14 +208,13 @@ int alloc_planes(cg_grid* g, int lmax) {
     return CG_OK;
 }
 
-// Empty every column.  Only len / top / topz0 are cleared: plane slots at or above a column's
+// Empty every column.  Only len / top are cleared: plane slots at or above a column's
 // length hold unspecified data and nothing reads them.
 int zero_planes(cg_grid* g, bool all = true) {
     (void)all;
     ProfScope ps(g, CG_K_CLEAR);
     HIPCHK(g, hipMemsetAsync(g->len, 0, g->N, g->stream));
     HIPCHK(g, hipMemsetAsync(g->top, 0, 4 * g->N, g->stream));
-    HIPCHK(g, hipMemsetAsync(g->topz0, 0, 2 * g->N, g->stream));
     g->split = true; g->nextp = 0;
     g->len_bound = 0; g->has_gaps = false; g->has_cavity = false;
     return CG_OK;
@@ -491,6 +488,19 @@ static int stencil_bands(int nx, int th, int R, bool has_lower, bool has_upper, 
     return n;
 }
 
+// tiles per super-tile of the lateral kernels (tuning knobs: env CG_SUPI, CG_SUPJ)
+static int sup_tiles(bool along_j) {
+    static int vi = [] { const char* e = getenv("CG_SUPI"); int x = e ? atoi(e) : 2; return (x >= 1 && x <= 16) ? x : 2; }();
+    static int vj = [] { const char* e = getenv("CG_SUPJ"); int x = e ? atoi(e) : 4; return (x >= 1 && x <= 16) ? x : 4; }();
+    return along_j ? vj : vi;
+}
+// blocks of a launch over tile_in x tiles_j tiles: whole super-tiles, a multiple of 8 of them
+static unsigned sup_grid(GridView& gv, int t0, int tile_in, int tiles_j) {
+    gv.tile_i0 = t0; gv.tile_in = tile_in; gv.sup_i = sup_tiles(false); gv.sup_j = sup_tiles(true);
+    const long n_s = (long)((tile_in + gv.sup_i - 1) / gv.sup_i) * ((tiles_j + gv.sup_j - 1) / gv.sup_j);
+    return (unsigned)(((n_s + 7) / 8) * 8 * gv.sup_i * gv.sup_j);
+}
+
 int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t_eff, int R, ConfKernel* K, int only_len,
                    const uint8_t* halo_lo, const uint8_t* halo_up, int P, int part = PART_ALL) {
     GridView gv = view(g);
@@ -511,8 +521,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
         const int tis = 1024 / TT;                                                                             \
         const int nb = stencil_bands(g->nx, tis, R, halo_lo != nullptr, halo_up != nullptr, part, bands);      \
         for (int b_ = 0; b_ < nb; b_++) {                                                                      \
-            gv.tile_i0 = bands[b_].t0;                                                                         \
-            const dim3 gridS(bands[b_].n * ((g->ny + TT - 1) / TT));                                           \
+            const dim3 gridS(sup_grid(gv, bands[b_].t0, bands[b_].n, (g->ny + TT - 1) / TT));                  \
             hipLaunchKernelGGL((k_stencil_sym<RR, TT, E, S>), gridS, blk, 0, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
                                tab, K->d_taps64_sym, K->ntaps64_sym, g->d_flags, g->d_stats);                  \
         }                                                                                                      \
@@ -539,8 +548,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
             HIPCHK(g, hipFuncSetAttribute((const void*)k_stencil_apply<E, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         const int nb = stencil_bands(g->nx, TI, R, halo_lo != nullptr, halo_up != nullptr, part, bands);       \
         for (int b_ = 0; b_ < nb; b_++) {                                                                      \
-            gv.tile_i0 = bands[b_].t0;                                                                         \
-            const dim3 grid(bands[b_].n * ((g->ny + TJ - 1) / TJ));                                            \
+            const dim3 grid(sup_grid(gv, bands[b_].t0, bands[b_].n, (g->ny + TJ - 1) / TJ));                   \
             hipLaunchKernelGGL((k_stencil_apply<E, S>), grid, blk, lds, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
                                K->d_taps, K->ntaps, K->d_taps64, K->ntaps64, only_len, g->d_flags, g->d_stats); \
         }                                                                                                      \
@@ -771,7 +779,7 @@ int cg_destroy(cg_grid* g) {
     free_planes(g);
     for (auto m : g->masks) if (m) (void)hipFree(m);
     for (auto k : g->kcache) free_kernel(k);
-    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.rec); (void)hipFree(s.second.top); (void)hipFree(s.second.topz0); (void)hipFree(s.second.link); (void)hipFree(s.second.prv); }
+    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.rec); (void)hipFree(s.second.top); (void)hipFree(s.second.link); (void)hipFree(s.second.prv); }
     if (!g->halo_external) for (auto h : g->halo) if (h) (void)hipFree(h);
     for (auto& r : g->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
@@ -1527,7 +1535,7 @@ int cg_snapshot_save(cg_grid* g, int slot) {
     cg_snapshot_drop(g, slot);
     Snapshot s; size_t S = g->N * (size_t)g->lmax;
     HIPCHK(g, hipMalloc(&s.len, std::max<size_t>(g->N, 4))); HIPCHK(g, hipMalloc(&s.rec, std::max<size_t>(4 * S, 4)));
-    HIPCHK(g, hipMalloc(&s.top, std::max<size_t>(4 * g->N, 16))); HIPCHK(g, hipMalloc(&s.topz0, std::max<size_t>(2 * g->N, 16)));
+    HIPCHK(g, hipMalloc(&s.top, std::max<size_t>(4 * g->N, 16)));
     HIPCHK(g, hipMalloc(&s.link, std::max<size_t>(g->N, 16))); HIPCHK(g, hipMalloc(&s.prv, std::max<size_t>(S, 16)));
     HIPCHK(g, hipMemcpyAsync(s.link, g->link, g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(s.prv, g->prv, S, hipMemcpyDeviceToDevice, g->stream));
@@ -1535,7 +1543,6 @@ int cg_snapshot_save(cg_grid* g, int slot) {
     HIPCHK(g, hipMemcpyAsync(s.len, g->len, g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(s.rec, g->rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(s.top, g->top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(s.topz0, g->topz0, 2 * g->N, hipMemcpyDeviceToDevice, g->stream));
     s.split = g->split;
     s.lmax = g->lmax; s.lmax_vis = g->lmax_vis; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps; s.has_cavity = g->has_cavity;
     g->snaps[slot] = s;
@@ -1553,7 +1560,6 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     HIPCHK(g, hipMemcpyAsync(g->len, s.len, g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->rec, s.rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->top, s.top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(g->topz0, s.topz0, 2 * g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->link, s.link, g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->prv, s.prv, S, hipMemcpyDeviceToDevice, g->stream));
     g->nextp = s.nextp;
@@ -1568,7 +1574,7 @@ int cg_snapshot_drop(cg_grid* g, int slot) {
     auto it = g->snaps.find(slot);
     if (it == g->snaps.end()) return CG_OK;
     HIPCHK(g, hipStreamSynchronize(g->stream));
-    (void)hipFree(it->second.len); (void)hipFree(it->second.rec); (void)hipFree(it->second.top); (void)hipFree(it->second.topz0);
+    (void)hipFree(it->second.len); (void)hipFree(it->second.rec); (void)hipFree(it->second.top);
     (void)hipFree(it->second.link); (void)hipFree(it->second.prv);
     g->snaps.erase(it);
     return CG_OK;

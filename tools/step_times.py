@@ -14,7 +14,8 @@ g = fem_amd.ColumnGrid(dx=2.0, dy=2.0, slab=(n, n, 0, n))
 specs = flows.mask_specs(2.0 * n)
 names = sorted({s["mask"] for s in flow if s["mask"]})
 masks = bench.build_masks(fem_amd, flows, g, specs, names, n, n, 0, 2.0 * n, 2.0 * n, dev)
-for rep in range(2):
+REPS = int(os.environ.get("REPS", "2"))      # COMPACT=1 prints every pass after the first
+for rep in range(REPS):
     g.createNewGrid(); g.sync()
     rows = []
     for k, s in enumerate(flow):
