@@ -14,9 +14,12 @@
 //                what the kernels that restructure whole columns work on (strip, cavity, CMP,
 //                wet etch, ALD, upload).
 //
-//   split form   len[c] u8, top[c] u32 = the top interval (0: empty column), link[c] u8 = the
-//                plane holding the interval below it (whose z1 is the top's bottom), and for an
-//                interval stored in plane p: rec[p*N + c], prv[p*N + c] u8 = the plane of the one below.
+//   split form   top[c] u32 = the top interval (0: empty column), link[c] u8 = the plane holding
+//                the interval below it (whose z1 is the top's bottom; LINK_NONE if there is none),
+//                and for an interval stored in plane p: rec[p*N + c], prv[p*N + c] u8 = the plane of
+//                the one below (LINK_NONE for the bottom interval).  len[c] is NOT kept up to date
+//                by the 4-columns-per-thread kernels -- the chain says everything they need -- and
+//                is recounted from the chain (k_relen) before anything reads it.
 //                What the vertical and lateral steps work on: they only ever look at the top, so
 //                extend / partial etch / "material differs" touch streams whose addresses do not
 //                depend on the column length.  An append pushes the old top into the plane P of
@@ -46,8 +49,8 @@ struct GridView {
     uint32_t* rec;
     uint32_t* top;      // split form: the top interval of every column (0 for an empty column)
     uint32_t* top_w;    // where updated tops are stored: top itself, or the other buffer in a lateral step
-    uint8_t*  link;     // split form: plane that holds the interval below the top (len >= 2)
-    uint8_t*  prv;      // split form: prv[p*N + c] = plane of the interval below the one stored in plane p
+    uint8_t*  link;     // split form: plane that holds the interval below the top, LINK_NONE if len < 2
+    uint8_t*  prv;      // split form: prv[p*N + c] = plane of the interval below the one stored in plane p, or LINK_NONE
     int       P;        // split form: the plane this launch pushes old tops into (-1: it cannot append)
     int       split;    // 1: split form (see below); 0: whole form, planes hold intervals 0..len-1 by index
     size_t    N;        // columns of this handle
@@ -61,6 +64,7 @@ struct GridView {
     double    inv_zs;   // 1/zs, rounded once on the host
 };
 
+constexpr int LINK_NONE = 255;              // link / prv: no interval below (so at most 255 planes are ever linked)
 constexpr uint32_t REC_HOLE = 1u << 24;     // a vertical gap, not a layer
 constexpr uint32_t REC_MARK = 2u << 24;     // scratch bit of the flood fill (strip_connected)
 constexpr uint32_t REC_RUN  = 4u << 24;     // the nearest layer below has the same material
@@ -127,17 +131,14 @@ __device__ __forceinline__ void load_column(const GridView& g, size_t c, int l, 
 // looks up the new bottom and the new link.
 __device__ __forceinline__ void reload_top(const GridView& g, size_t c, int& l, uint32_t& r, unsigned& z0q, int& lk) {
     r = g.rec[(size_t)lk * g.N + c];
-    int p2 = l > 1 ? g.prv[(size_t)lk * g.N + c] : 0;
-    uint32_t b = l > 1 ? g.rec[(size_t)p2 * g.N + c] : 0;
+    int p2 = g.prv[(size_t)lk * g.N + c];
     if (rec_hole(r)) {
         l -= 1;
-        if (l == 0) { r = 0; z0q = 0; return; }
-        r = b;
-        const int p3 = l > 1 ? g.prv[(size_t)p2 * g.N + c] : 0;
-        b = l > 1 ? g.rec[(size_t)p3 * g.N + c] : 0;
-        p2 = p3;
+        if (l == 0) { r = 0; z0q = 0; lk = LINK_NONE; return; }
+        r = g.rec[(size_t)p2 * g.N + c];
+        p2 = g.prv[(size_t)p2 * g.N + c];
     }
-    z0q = rec_z1(b);
+    z0q = p2 != LINK_NONE ? rec_z1(g.rec[(size_t)p2 * g.N + c]) : 0u;
     lk = p2;
 }
 
@@ -183,10 +184,10 @@ __device__ __forceinline__ int apply_etch_at(const GridView& g, size_t c, int l,
     int removed = 0; bool touched = false;
     const int l0 = l;
     uint32_t r = g.top[c];
-    int lk = l > 1 ? g.link[c] : 0;
-    unsigned z0q = l > 1 ? rec_z1(g.rec[(size_t)lk * g.N + c]) : 0u;
+    int lk = g.link[c];
+    unsigned z0q = lk != LINK_NONE ? rec_z1(g.rec[(size_t)lk * g.N + c]) : 0u;
     while (etch_round(g, r, z0q, l, remaining, matId, isAll, touched, removed)) {
-        if (l > 0) reload_top(g, c, l, r, z0q, lk); else { r = 0; z0q = 0; }
+        if (l > 0) reload_top(g, c, l, r, z0q, lk); else { r = 0; z0q = 0; lk = LINK_NONE; }
     }
     if (touched) {
         g.top_w[c] = r;
@@ -196,30 +197,29 @@ __device__ __forceinline__ int apply_etch_at(const GridView& g, size_t c, int l,
 }
 
 // bottom of the top run of matId (script_columngrid.js:646-660); the top layer (record r, bottom
-// z0q) is known to be matId.  Gaps do not interrupt the run (the reference only compares
+// z0q, link lk) is known to be matId.  Gaps do not interrupt the run (the reference only compares
 // materials).  The RUN flag of a record says that the nearest layer below it has the same
 // material, so the usual case -- the run is the top layer alone -- needs no look at the stack.
-__device__ __forceinline__ double floor_of_top_run(const GridView& g, size_t c, int l, int matId, uint32_t r, unsigned z0q, unsigned& scanned) {
+__device__ __forceinline__ double floor_of_top_run(const GridView& g, size_t c, int lk, int matId, uint32_t r, unsigned z0q, unsigned& scanned) {
     scanned++;
     if (!(r & REC_RUN)) return (double)z0q * g.zs;
-    int m = l - 1;                 // intervals below the run found so far; p = plane of the topmost of them
-    int p = m > 0 ? g.link[c] : 0;
-    while (m > 0) {
+    int p = lk;                    // plane of the topmost interval not known to belong to the run
+    while (p != LINK_NONE) {
         const uint32_t b = g.rec[(size_t)p * g.N + c];
         if (rec_hole(b)) {         // look through the gap at the layer under it
-            if (m == 1) break;
             const int p2 = g.prv[(size_t)p * g.N + c];
+            if (p2 == LINK_NONE) break;
             const uint32_t b2 = g.rec[(size_t)p2 * g.N + c];
             if (rec_mat(b2) != matId) break;
-            m -= 2; scanned++;
-            if (m > 0) p = g.prv[(size_t)p2 * g.N + c];
+            scanned++;
+            p = g.prv[(size_t)p2 * g.N + c];
             continue;
         }
         if (rec_mat(b) != matId) break;
-        m -= 1; scanned++;
-        if (m > 0) p = g.prv[(size_t)p * g.N + c];
+        scanned++;
+        p = g.prv[(size_t)p * g.N + c];
     }
-    return m > 0 ? (double)rec_z1(g.rec[(size_t)p * g.N + c]) * g.zs : 0.0;
+    return p != LINK_NONE ? (double)rec_z1(g.rec[(size_t)p * g.N + c]) * g.zs : 0.0;
 }
 
 // block-wide accumulation of statistics into global counters
@@ -294,61 +294,55 @@ __device__ __forceinline__ void st_u16x4(uint16_t* p, u16x4 v) { *(u16x4*)p = v;
 __device__ __forceinline__ unsigned open_bits(u8x4 mk) { return (mk[0] ? 1u : 0u) | (mk[1] ? 2u : 0u) | (mk[2] ? 4u : 0u) | (mk[3] ? 8u : 0u); }
 
 // _depoAtTop_ on the open columns of a group: column j grows by dz[j] (> 0).  tv = the 4 tops,
-// lk = their links.  Returns whether the group's tops were stored.
+// lk = their links.  Returns whether the group's tops were stored.  The host launches this form
+// only while every column has a plane to spare (the reference's growth rule needs the lengths).
 template <bool STATS>
-__device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
-                                            u32x4 tv, u8x4 lk, int* __restrict__ flags, unsigned& n_ext, unsigned& n_app) {
-    u32x4 nv = tv; u8x4 nl = ln;
-    unsigned ext = 0, app = 0;
+__device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsigned open, const double (&dz)[4], int matId,
+                                            u32x4 tv, u8x4 lk, unsigned& n_ext, unsigned& n_app) {
+    u32x4 nv = tv;
+    unsigned ext = 0, app = 0, push = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         if (!((open >> j) & 1)) continue;
-        const int l = ln[j];
-        const uint32_t r = l > 0 ? tv[j] : 0;
+        const uint32_t r = tv[j];                              // 0: empty column
         const uint32_t q = quantz((double)rec_z1(r) * g.zs + dz[j], g.zs, g.inv_zs);
-        if (l > 0 && rec_mat(r) == matId) { nv[j] = rec_with_z1(r, q); ext |= 1u << j; }
-        else if (l >= g.lmax) flags[0] = 1;      // no plane left: the host grows the planes and re-runs these columns
-        else { nv[j] = rec_make(q, matId); nl[j] = (uint8_t)(l + 1); app |= 1u << j; }
+        if (r != 0 && rec_mat(r) == matId) { nv[j] = rec_with_z1(r, q); ext |= 1u << j; }
+        else { nv[j] = rec_make(q, matId); app |= 1u << j; if (r != 0) push |= 1u << j; }
     }
     if (!(ext | app)) return false;
-    if (app) {
+    if (push) {
         // the old tops go into this step's plane (whatever the column lengths: one dense line per
         // 32 columns), each with the link to what was below it
         const size_t b = (size_t)g.P * g.N + c0;
         u8x4 nk = lk;
-        if (app == 15u) {
-            if (as_u32(ln) != 0u) {                            // (columns that were empty push nothing)
-                st_rec4(g.rec + b, tv);
-                st_u8x4(g.prv + b, lk);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) if (ln[j]) nk[j] = (uint8_t)g.P;
+        if (push == 15u) {
+            st_rec4(g.rec + b, tv);
+            st_u8x4(g.prv + b, lk);
+            nk = splat4(g.P);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                if (!((app >> j) & 1)) continue;
-                if (ln[j]) { g.rec[b + j] = tv[j]; g.prv[b + j] = lk[j]; nk[j] = (uint8_t)g.P; }
+                if (!((push >> j) & 1)) continue;
+                g.rec[b + j] = tv[j]; g.prv[b + j] = lk[j]; nk[j] = (uint8_t)g.P;
             }
         }
-        st_u8x4(g.len + c0, nl);
         st_u8x4(g.link + c0, nk);
-        if (STATS) n_app += __popc(app);
     }
+    if (STATS) n_app += __popc(app);
     st_rec4(g.top_w + c0, nv);
     if (STATS) n_ext += __popc(ext);
     return true;
 }
 
-// The intervals below the tops of the columns in `want` (only those with l > 1 have one): their
+// The intervals below the tops of the columns in `want` (those whose link is not LINK_NONE): their
 // records b[] -- the top's bottom is rec_z1(b), and b is the new top should the whole top layer
 // go -- and their links pv[] (loaded along with the records: fetching them only once a layer is
 // known to go costs a round trip more per removed layer, measured 10 % on such steps).  Columns
 // whose links name the same plane (they were pushed by the same step) share the vector loads.
-__device__ __forceinline__ void load_below4(const GridView& g, size_t c0, unsigned want, const int (&l)[4], const int (&lk)[4],
-                                            uint32_t (&b)[4], int (&pv)[4]) {
+__device__ __forceinline__ void load_below4(const GridView& g, size_t c0, unsigned want, const int (&lk)[4], uint32_t (&b)[4], int (&pv)[4]) {
     unsigned todo = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) if (((want >> j) & 1) && l[j] > 1) todo |= 1u << j;
+    for (int j = 0; j < 4; j++) if (((want >> j) & 1) && lk[j] != LINK_NONE) todo |= 1u << j;
     while (todo) {
         const int j0 = __ffs(todo) - 1;
         const int p = lk[j0];
@@ -373,10 +367,9 @@ __device__ __forceinline__ void load_below4(const GridView& g, size_t c0, unsign
 // the caller has loaded already (b0 / pv0, see load_below4).  A column that loses its whole top
 // layer continues with the interval below it.
 template <bool STATS>
-__device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsigned open, u8x4 ln, const double (&dz)[4], int matId,
+__device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsigned open, const double (&dz)[4], int matId,
                                             bool isAll, u32x4 tv, u8x4 lkv, unsigned have, const uint32_t (&b0)[4], const int (&pv0)[4],
                                             unsigned& n_touched, unsigned& n_removed) {
-    int l[4] = {ln[0], ln[1], ln[2], ln[3]};
     int lk[4] = {lkv[0], lkv[1], lkv[2], lkv[3]};
     uint32_t r[4] = {tv[0], tv[1], tv[2], tv[3]};
     double rem[4] = {dz[0], dz[1], dz[2], dz[3]};
@@ -385,27 +378,27 @@ __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsign
     unsigned dirty = 0, popped = 0, act = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++)
-        if (((open >> j) & 1) && l[j] > 0 && rem[j] > CG_EPS && (isAll || rec_mat(r[j]) == matId)) act |= 1u << j;   // cg1:565-569
+        if (((open >> j) & 1) && r[j] != 0 && rem[j] > CG_EPS && (isAll || rec_mat(r[j]) == matId)) act |= 1u << j;   // cg1:565-569
     while (act) {
-        load_below4(g, c0, act & ~have, l, lk, b, pv);
+        load_below4(g, c0, act & ~have, lk, b, pv);
         have = 0;
         unsigned next = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (!((act >> j) & 1)) continue;
-            const uint32_t below = l[j] > 1 ? b[j] : 0u;
+            const bool has_below = lk[j] != LINK_NONE;
+            const uint32_t below = has_below ? b[j] : 0u;
             const double z1 = (double)rec_z1(r[j]) * g.zs, z0 = (double)rec_z1(below) * g.zs, thick = z1 - z0;
             dirty |= 1u << j;
             if (rem[j] < thick - CG_EPS) { r[j] = rec_with_z1(r[j], quantz(z1 - rem[j], g.zs, g.inv_zs)); rem[j] = 0; continue; }   // cg1:574-578
-            rem[j] -= thick; l[j] -= 1; popped |= 1u << j;                                                                          // cg1:579-587
+            rem[j] -= thick; popped |= 1u << j;                                                                                     // cg1:579-587
             if (STATS) n_removed += 1;
-            if (l[j] == 0) { r[j] = 0; lk[j] = 0; continue; }
-            r[j] = below; lk[j] = l[j] > 1 ? pv[j] : 0;
+            if (!has_below) { r[j] = 0; continue; }
+            r[j] = below; lk[j] = pv[j];
             if (rec_hole(r[j])) {                              // a gap under the removed layer goes with it
-                l[j] -= 1;
-                if (l[j] == 0) { r[j] = 0; lk[j] = 0; continue; }
+                if (lk[j] == LINK_NONE) { r[j] = 0; continue; }
                 const size_t at = (size_t)lk[j] * g.N + c0 + j;
-                r[j] = g.rec[at]; lk[j] = l[j] > 1 ? g.prv[at] : 0;
+                r[j] = g.rec[at]; lk[j] = g.prv[at];
             }
             if (rem[j] > CG_EPS && (isAll || rec_mat(r[j]) == matId)) next |= 1u << j;
         }
@@ -415,9 +408,7 @@ __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsign
         u32x4 nv; nv[0] = r[0]; nv[1] = r[1]; nv[2] = r[2]; nv[3] = r[3];
         st_rec4(g.top_w + c0, nv);
         if (popped) {
-            u8x4 nl; nl[0] = (uint8_t)l[0]; nl[1] = (uint8_t)l[1]; nl[2] = (uint8_t)l[2]; nl[3] = (uint8_t)l[3];
             u8x4 nk; nk[0] = (uint8_t)lk[0]; nk[1] = (uint8_t)lk[1]; nk[2] = (uint8_t)lk[2]; nk[3] = (uint8_t)lk[3];
-            st_u8x4(g.len + c0, nl);
             st_u8x4(g.link + c0, nk);
         }
     }
@@ -447,16 +438,15 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
         if (tile >= ntiles) continue;
         if (row_tiles > 1) { const size_t r = tile / row_tiles, q = tile - r * row_tiles; tile = r * row_tiles + (q + r) % row_tiles; }
         const size_t gbase = tile * tile_groups + threadIdx.x;
-        u8x4 ln[U], lk[U]; unsigned open[U]; u32x4 tv[U];
+        u8x4 lk[U]; unsigned open[U]; u32x4 tv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t gi = gbase + (size_t)u * 256;
-            open[u] = 0; ln[u] = splat4(0); lk[u] = splat4(0); tv[u] = (u32x4)(0);
+            open[u] = 0; lk[u] = splat4(0); tv[u] = (u32x4)(0);
             if (gi < ngroups) {
                 const size_t c0 = gi << 2;
                 open[u] = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
                 if (open[u]) {
-                    ln[u] = ld_u8x4(g.len + c0);
                     lk[u] = ld_u8x4(g.link + c0);
                     tv[u] = ld_rec4(g.top + c0);
                 }
@@ -468,8 +458,8 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
             const size_t c0 = (gbase + (size_t)u * 256) << 2;
             if (STATS) loc[0] += __popc(open[u]);
             if (ETCH) { const uint32_t nb[4] = {0, 0, 0, 0}; const int np[4] = {0, 0, 0, 0};
-                        etch_group4<STATS>(g, c0, open[u], ln[u], dz, matId, isAll, tv[u], lk[u], 0u, nb, np, loc[1], loc[2]); }
-            else depo_group4<STATS>(g, c0, open[u], ln[u], dz, matId, tv[u], lk[u], flags, loc[1], loc[2]);
+                        etch_group4<STATS>(g, c0, open[u], dz, matId, isAll, tv[u], lk[u], 0u, nb, np, loc[1], loc[2]); }
+            else depo_group4<STATS>(g, c0, open[u], dz, matId, tv[u], lk[u], loc[1], loc[2]);
         }
     }
     if (STATS) {
@@ -662,8 +652,9 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 if (ETCH) {
                     float F = 0.f;
                     if (!isAll && l > 0) {
-                        const unsigned z0q = l > 1 ? rec_z1(g.rec[(size_t)g.link[c] * g.N + c]) : 0u;
-                        F = (float)fmax(0.0, floor_of_top_run(g, c, l, matId, g.top[c], z0q, loc[3]));
+                        const int lk = g.link[c];
+                        const unsigned z0q = lk != LINK_NONE ? rec_z1(g.rec[(size_t)lk * g.N + c]) : 0u;
+                        F = (float)fmax(0.0, floor_of_top_run(g, c, lk, matId, g.top[c], z0q, loc[3]));
                     }
                     float hp = fmaxf(0.f, fmaxf(F, m[r]));             // cg1:725
                     double dz = (double)own[r] - (double)hp;
@@ -856,7 +847,6 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
 #undef CG_OP
 #undef CG_ADD
             // ---- per-column update
-            const u8x4 ln = ld_u8x4(g.len + c0);
             const u8x4 lkv = ld_u8x4(g.link + c0);
             double dz[4] = {0, 0, 0, 0};
             unsigned open = 0;
@@ -868,25 +858,24 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                     const double d = (double)m[c] - (double)own[c];          // cg1:534-537
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) stored = depo_group4<STATS>(g, c0, open, ln, dz, matId, tv, lkv, flags, loc[1], loc[2]);
+                if (open) stored = depo_group4<STATS>(g, c0, open, dz, matId, tv, lkv, loc[1], loc[2]);
             } else {
                 // every etchable column needs the bottom of its top layer: for the floor (when a
                 // material is named) and for the cut itself
-                const int l4[4] = {ln[0], ln[1], ln[2], ln[3]};
                 const int k4[4] = {lkv[0], lkv[1], lkv[2], lkv[3]};
                 uint32_t b4[4] = {0, 0, 0, 0}; int p4[4] = {0, 0, 0, 0};
-                load_below4(g, c0, act, l4, k4, b4, p4);
+                load_below4(g, c0, act, k4, b4, p4);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     if (!((act >> c) & 1)) continue;
                     // floor = bottom of the top run of matId (cg1:646-660)
                     float F = 0.f;
-                    if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, ln[c], matId, tv[c], l4[c] > 1 ? rec_z1(b4[c]) : 0u, loc[3]));
+                    if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, k4[c], matId, tv[c], k4[c] != LINK_NONE ? rec_z1(b4[c]) : 0u, loc[3]));
                     const float hpv = fmaxf(0.f, fmaxf(F, m[c]));                     // cg1:725
                     const double d = (double)own[c] - (double)hpv;
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) stored = etch_group4<STATS>(g, c0, open, ln, dz, matId, isAll, tv, lkv, act, b4, p4, loc[1], loc[2]);
+                if (open) stored = etch_group4<STATS>(g, c0, open, dz, matId, isAll, tv, lkv, act, b4, p4, loc[1], loc[2]);
             }
         }
         if (!stored && g.top_w != g.top) st_rec4(g.top_w + c0, tv);       // columns that stay as they are
@@ -955,7 +944,7 @@ __global__ __launch_bounds__(256) void k_mask_normalise(const uint8_t* __restric
 // ------------------------------------------------------------------------------------------
 // reductions and checks
 // ------------------------------------------------------------------------------------------
-// out[0] = max top z1q, out[1] = max len
+// out[0] = max top z1q, out[1] = max len (len must be current, see k_relen)
 __global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restrict__ out) {
     unsigned mq = 0, ml = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -971,6 +960,32 @@ __global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restric
         mq = a > mq ? a : mq; ml = b > ml ? b : ml;
     }
     if ((threadIdx.x & 63) == 0) { if (mq) atomicMax(&out[0], mq); if (ml) atomicMax(&out[1], ml); }
+}
+
+// split form: out[0] = max top z1q from the top stream alone (an empty column's top is 0)
+__global__ __launch_bounds__(256) void k_max_top_split(GridView g, unsigned* __restrict__ out) {
+    unsigned mq = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const uint32_t r = g.top[c];
+        const unsigned q = r ? rec_z1(r) : 0u;
+        mq = q > mq ? q : mq;
+    }
+    for (int o = 32; o > 0; o >>= 1) { unsigned a = __shfl_down(mq, o, 64); mq = a > mq ? a : mq; }
+    if ((threadIdx.x & 63) == 0 && mq) atomicMax(&out[0], mq);
+}
+
+// split form: len[c] recounted from the chain (the 4-columns-per-thread kernels do not maintain it)
+__global__ __launch_bounds__(256) void k_relen(GridView g) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        int l = 0;
+        if (g.top[c] != 0) {
+            l = 1;
+            for (int p = g.link[c]; p != LINK_NONE && l < 255; p = g.prv[(size_t)p * g.N + c]) l++;
+        }
+        g.len[c] = (uint8_t)l;
+    }
 }
 
 // whole form: out[0] = max number of layers (gap intervals not counted), out[1] = max len
@@ -1364,14 +1379,14 @@ __global__ __launch_bounds__(256) void k_promote(GridView g) {
         int below_mat = -1; uint32_t r = 0;
         for (int k = 0; k < l; k++) {
             r = g.rec[(size_t)k * g.N + c];
-            if (k > 0 && k < l - 1) g.prv[(size_t)k * g.N + c] = (uint8_t)(k - 1);
+            if (k < l - 1) g.prv[(size_t)k * g.N + c] = (uint8_t)(k > 0 ? k - 1 : LINK_NONE);
             if (rec_hole(r)) continue;
             const uint32_t want = (r & ~REC_RUN) | ((below_mat == rec_mat(r)) ? REC_RUN : 0u);
             if (want != r) { r = want; g.rec[(size_t)k * g.N + c] = r; }
             below_mat = rec_mat(r);
         }
         g.top[c] = l > 0 ? r : 0;
-        g.link[c] = (uint8_t)(l > 1 ? l - 2 : 0);
+        g.link[c] = (uint8_t)(l > 1 ? l - 2 : LINK_NONE);
     }
 }
 

@@ -57,7 +57,7 @@ struct ConfKernel {
 struct Snapshot {
     uint8_t* len = nullptr; uint32_t* rec = nullptr; uint32_t* top = nullptr;
     uint8_t* link = nullptr; uint8_t* prv = nullptr; int nextp = 0;
-    bool split = true;
+    bool split = true, len_valid = true;
     int lmax = 0; int lmax_vis = 0; int len_bound = 0; bool has_gaps = false, has_cavity = false;
 };
 
@@ -85,6 +85,7 @@ struct cg_grid {
     uint8_t* link = nullptr; uint8_t* prv = nullptr;      // split form: chain of a column's intervals through the planes
     int nextp = 0;                                        // split form: first plane no interval lives in yet
     bool split = true;                                    // which form the columns are in right now
+    bool len_valid = true;                                // split form: len[] agrees with the chains (see ensure_len)
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<uint8_t*> masks;
     std::deque<ConfKernel*> kcache;
@@ -208,14 +209,15 @@ int alloc_planes(cg_grid* g, int lmax) {
     return CG_OK;
 }
 
-// Empty every column.  Only len / top are cleared: plane slots at or above a column's
+// Empty every column.  Only len / top / link are reset: plane slots at or above a column's
 // length hold unspecified data and nothing reads them.
 int zero_planes(cg_grid* g, bool all = true) {
     (void)all;
     ProfScope ps(g, CG_K_CLEAR);
     HIPCHK(g, hipMemsetAsync(g->len, 0, g->N, g->stream));
     HIPCHK(g, hipMemsetAsync(g->top, 0, 4 * g->N, g->stream));
-    g->split = true; g->nextp = 0;
+    HIPCHK(g, hipMemsetAsync(g->link, 0xff, g->N, g->stream));        // LINK_NONE: nothing below
+    g->split = true; g->nextp = 0; g->len_valid = true;
     g->len_bound = 0; g->has_gaps = false; g->has_cavity = false;
     return CG_OK;
 }
@@ -223,6 +225,16 @@ int zero_planes(cg_grid* g, bool all = true) {
 // The kernels of the vertical and lateral steps work on the split form, the ones that
 // restructure whole columns (strip, cavity, CMP, wet etch, ALD, upload) on whole stacks.
 int refresh_len_bound(cg_grid* g, unsigned* topq_out);
+// The vertical and lateral kernels that own 4 columns per thread work from the chains alone and
+// leave len[] behind; whatever reads len[] of a grid in split form calls this first.
+int ensure_len(cg_grid* g) {
+    if (g->len_valid || !g->split) { g->len_valid = true; return CG_OK; }
+    ProfScope ps(g, CG_K_OTHER);
+    hipLaunchKernelGGL(k_relen, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g));
+    HIPCHK(g, hipGetLastError());
+    g->len_valid = true;
+    return CG_OK;
+}
 int ensure_split(cg_grid* g) {
     if (g->split) return CG_OK;
     if (g->len_bound > g->lmax) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; }
@@ -235,6 +247,7 @@ int ensure_split(cg_grid* g) {
 }
 int ensure_whole(cg_grid* g) {
     if (!g->split) return CG_OK;
+    { int rc = ensure_len(g); if (rc) return rc; }
     ProfScope ps(g, CG_K_OTHER);
     hipLaunchKernelGGL(k_demote, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g));
     HIPCHK(g, hipGetLastError());
@@ -271,6 +284,7 @@ int read_flags(cg_grid* g, int out[4]) {
 }
 
 int refresh_len_bound(cg_grid* g, unsigned* topq_out) {
+    { int rc = ensure_len(g); if (rc) return rc; }
     HIPCHK(g, hipMemsetAsync(g->d_red, 0, 2 * sizeof(unsigned), g->stream));
     { ProfScope ps(g, CG_K_REDUCE);
       hipLaunchKernelGGL(k_max_top, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_red); }
@@ -429,11 +443,11 @@ int ensure_stencil_scratch(cg_grid* g, int R, bool need_halo) {
 // its writes are dense whatever the column lengths.  When the planes run out the columns are
 // compacted (whole form and back: interval k in plane k), which frees every plane above max(len)-2.
 int take_append_plane(cg_grid* g, int* P) {
-    if (g->nextp >= g->lmax) {
+    if (g->nextp >= std::min(g->lmax, 255)) {                  // (255 = LINK_NONE is never a link)
         int rc = ensure_whole(g); if (rc) return rc;
         rc = refresh_len_bound(g, nullptr); if (rc) return rc;
         rc = ensure_split(g); if (rc) return rc;
-        if (g->nextp >= g->lmax) { rc = grow_planes(g); if (rc) return rc; }
+        if (g->nextp >= std::min(g->lmax, 255)) { rc = grow_planes(g); if (rc) return rc; }
     }
     *P = g->nextp++;
     return CG_OK;
@@ -445,26 +459,32 @@ int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
     { int rcp = take_append_plane(g, &P); if (rcp) return rcp; }
     bool may_overflow = g->len_bound >= g->lmax;
     if (may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; may_overflow = g->len_bound >= g->lmax; }
-    if (may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
     const dim3 grid(blocks_for(g->N)), blk(256);
-    ProfScope ps(g, CG_K_DEPO_VERTICAL);
     GridView gv = view(g); gv.P = P;
-    if (g->N % 4 == 0) {        // 4 columns per thread
+    if (g->N % 4 == 0 && !may_overflow) {        // 4 columns per thread, no look at the lengths
+        ProfScope ps(g, CG_K_DEPO_VERTICAL);
         launch_vertical<false>(g, mask, mat, t, P);
+        HIPCHK(g, hipGetLastError());
+        g->len_valid = false;
     } else {
+        // a column may be full: the one-column kernel reads the lengths, reports an append that
+        // found no room (script_columngrid.js:418) and is re-run for those columns after the growth
+        int rc = ensure_len(g); if (rc) return rc;
+        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
+        ProfScope ps(g, CG_K_DEPO_VERTICAL);
         if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<false, true>), grid, blk, 0, g->stream, gv, mask, mat, t, -1, g->d_flags, g->d_stats);
         else hipLaunchKernelGGL((k_vertical_1<false, false>), grid, blk, 0, g->stream, gv, mask, mat, t, -1, g->d_flags, g->d_stats);
-    }
-    HIPCHK(g, hipGetLastError());
-    if (may_overflow) {
-        int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
-        if (fl[0]) {
-            const int oldL = g->lmax;
-            rc = grow_planes(g); if (rc) return rc;
-            gv = view(g); gv.P = P;
-            if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<false, true>), grid, blk, 0, g->stream, gv, mask, mat, t, oldL, g->d_flags, g->d_stats);
-            else hipLaunchKernelGGL((k_vertical_1<false, false>), grid, blk, 0, g->stream, gv, mask, mat, t, oldL, g->d_flags, g->d_stats);
-            HIPCHK(g, hipGetLastError());
+        HIPCHK(g, hipGetLastError());
+        if (may_overflow) {
+            int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
+            if (fl[0]) {
+                const int oldL = g->lmax;
+                rc = grow_planes(g); if (rc) return rc;
+                gv = view(g); gv.P = P;
+                if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<false, true>), grid, blk, 0, g->stream, gv, mask, mat, t, oldL, g->d_flags, g->d_stats);
+                else hipLaunchKernelGGL((k_vertical_1<false, false>), grid, blk, 0, g->stream, gv, mask, mat, t, oldL, g->d_flags, g->d_stats);
+                HIPCHK(g, hipGetLastError());
+            }
         }
     }
     if (g->len_bound < 255) g->len_bound += 1;
@@ -502,14 +522,19 @@ static unsigned sup_grid(GridView& gv, int t0, int tile_in, int tiles_j) {
 }
 
 int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t_eff, int R, ConfKernel* K, int only_len,
-                   const uint8_t* halo_lo, const uint8_t* halo_up, int P, int part = PART_ALL) {
+                   const uint8_t* halo_lo, const uint8_t* halo_up, int P, int part = PART_ALL, bool keep_len = false) {
+    // keep_len: a column may be full, so the lengths matter -> the general kernel, which reads and
+    // maintains them; otherwise the symmetric kernel where it applies, which leaves them behind
+    const bool sym = only_len < 0 && !keep_len && K->sym_ok && g->ny % 4 == 0 && !getenv("CG_NO_SYM");
+    if (!sym) { int rcl = ensure_len(g); if (rcl) return rcl; }
     GridView gv = view(g);
     gv.top_w = g->top_alt; gv.P = P;
     const size_t lds = stencil_lds_bytes(R);
     const dim3 blk(256);
     Band bands[2];
     ProfScope ps(g, etch ? CG_K_STENCIL_ETCH : CG_K_STENCIL_DEPOSIT);
-    if (only_len < 0 && K->sym_ok && g->ny % 4 == 0 && !getenv("CG_NO_SYM")) {
+    if (sym) {
+        g->len_valid = false;
         const int tjs = sym_tile_cols();
 #define SYM(RR, TT, E, S)                                                                                      \
     do {                                                                                                       \
@@ -925,11 +950,16 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     if (latRange < std::min(g->dx, g->dy)) {                              // cg1:445, 609
         if (kind == CG_STENCIL_DEPOSIT) return run_depo_vertical(g, mask, mat, t);
         const dim3 grid(blocks_for(g->N)), blk(256);
-        ProfScope ps(g, CG_K_ETCH_VERTICAL);
-        if (g->N % 4 == 0) {    // 4 columns per thread
+        if (g->N % 4 == 0) {    // 4 columns per thread, no look at the lengths
+            ProfScope ps(g, CG_K_ETCH_VERTICAL);
             launch_vertical<true>(g, mask, mat, t, -1);
-        } else if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<true, true>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
-        else hipLaunchKernelGGL((k_vertical_1<true, false>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
+            g->len_valid = false;
+        } else {
+            int rcl = ensure_len(g); if (rcl) return rcl;
+            ProfScope ps(g, CG_K_ETCH_VERTICAL);
+            if (g->stats_on) hipLaunchKernelGGL((k_vertical_1<true, true>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
+            else hipLaunchKernelGGL((k_vertical_1<true, false>), grid, blk, 0, g->stream, view(g), mask, mat, t, -1, g->d_flags, g->d_stats);
+        }
         HIPCHK(g, hipGetLastError());
         return CG_OK;
     }
@@ -1006,7 +1036,7 @@ int cg_stencil_interior(cg_grid* g) {
     const Pending p = g->pend;
     const uint8_t* halo_lo = p.has_lower ? g->halo[2] : nullptr;           // not read by interior tiles; they tell the bands
     const uint8_t* halo_up = p.has_upper ? g->halo[3] : nullptr;
-    int rc = launch_stencil(g, etch, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, etch ? -1 : p.P, PART_INTERIOR);
+    int rc = launch_stencil(g, etch, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, etch ? -1 : p.P, PART_INTERIOR, !etch && p.may_overflow);
     if (rc) return rc;
     g->pend.interior_done = true;
     return CG_OK;
@@ -1030,7 +1060,7 @@ int cg_stencil_finish(cg_grid* g) {
         return CG_OK;
     }
 
-    int rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, p.P, part); if (rc) return rc;
+    int rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, p.P, part, p.may_overflow); if (rc) return rc;
     if (p.may_overflow) {
         int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
         if (fl[0]) {
@@ -1430,7 +1460,14 @@ int cg_release_scratch(cg_grid* g) {
 int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q) {
     NEED(g);
     unsigned q = 0;
-    int rc = refresh_len_bound(g, &q); if (rc) return rc;
+    if (g->split && !g->len_valid) {             // the tops alone say it; no need to recount the lengths
+        HIPCHK(g, hipMemsetAsync(g->d_red, 0, 2 * sizeof(unsigned), g->stream));
+        { ProfScope ps(g, CG_K_REDUCE);
+          hipLaunchKernelGGL(k_max_top_split, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_red); }
+        HIPCHK(g, hipGetLastError());
+        HIPCHK(g, hipMemcpyAsync(&q, g->d_red, sizeof q, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+    } else { int rc = refresh_len_bound(g, &q); if (rc) return rc; }
     if (top_q) *top_q = q;
     if (z_nm) { double z = (double)q * g->zscale; *z_nm = z > 0 ? z : 1; }      // cg2:103
     return CG_OK;
@@ -1474,6 +1511,7 @@ int cg_remove_top_layer(cg_grid* g, int i, int j) {
 int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
     NEED(g);
     if (!mat || !zpair || !len) return fail(g, CG_ERR_ARG, "null output array");
+    { int rc = ensure_len(g); if (rc) return rc; }
     const int L = g->lmax_vis;
     const size_t chunk = std::min<size_t>(g->N, (size_t)1 << 20);
     uint8_t *dm = nullptr, *dl = nullptr; uint16_t* dz = nullptr;
@@ -1544,7 +1582,7 @@ int cg_snapshot_save(cg_grid* g, int slot) {
     HIPCHK(g, hipMemcpyAsync(s.rec, g->rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(s.top, g->top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
     s.split = g->split;
-    s.lmax = g->lmax; s.lmax_vis = g->lmax_vis; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps; s.has_cavity = g->has_cavity;
+    s.len_valid = g->len_valid; s.lmax = g->lmax; s.lmax_vis = g->lmax_vis; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps; s.has_cavity = g->has_cavity;
     g->snaps[slot] = s;
     return CG_OK;
 }
@@ -1565,7 +1603,7 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     g->nextp = s.nextp;
     g->split = s.split;
     g->len_bound = s.len_bound; g->has_gaps = s.has_gaps; g->has_cavity = s.has_cavity;
-    g->lmax_vis = s.lmax_vis;
+    g->lmax_vis = s.lmax_vis; g->len_valid = s.len_valid;
     return CG_OK;
 }
 
@@ -1583,6 +1621,7 @@ int cg_snapshot_drop(cg_grid* g, int slot) {
 int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count, void** d_mat, void** d_zpair, void** d_len) {
     NEED(g);
     if ((axis != 0 && axis != 1) || !index || count < 1) return fail(g, CG_ERR_ARG, "bad slice request");
+    { int rc = ensure_len(g); if (rc) return rc; }
     const size_t line = axis == 0 ? (size_t)g->ny : (size_t)g->nx;
     const int L = g->lmax_vis;
     const size_t need = line * count;
@@ -1640,6 +1679,7 @@ int cg_index_from_pos(const cg_grid* g, int axis, double pos, int32_t* index) {
 int cg_checksum(cg_grid* g, uint64_t* sum) {
     NEED(g);
     if (!sum) return fail(g, CG_ERR_ARG, "null output");
+    { int rc = ensure_len(g); if (rc) return rc; }
     HIPCHK(g, hipMemsetAsync(g->d_sum, 0, sizeof(unsigned long long), g->stream));
     hipLaunchKernelGGL(k_checksum, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_sum);
     HIPCHK(g, hipGetLastError());
