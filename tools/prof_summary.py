@@ -74,7 +74,7 @@ for lb, v in tr.items():
                    "launches_profiled": min(v["nf"], v["nw"])}
 if res:
     with open(os.path.join(out, "traffic.json"), "w") as f:
-        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python3 bench.py --no-cpu; counters are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B; checked on the substrate step, which reads len only: 268 MB expected, 131 MiB-units reported)",
+        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python3 bench.py --no-cpu; counters are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B; checked on the vertical deposits, which read link (1 B) and top (4 B) per column: 1.342 GB expected at 16384^2, 0.671 GB-units reported)",
                    "kernels": res}, f, indent=1)
     print("== HBM traffic per launch (bytes)")
     for lb, v in sorted(res.items()):
