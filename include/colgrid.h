@@ -4,10 +4,11 @@
  * The library keeps one process-emulation grid per handle resident in HBM and runs
  * every process step as hand-written HIP kernels.  The grid is a 2-D array of columns
  * (index c = i*NY + j, j fastest); every column is a stack of (material, z0, z1) layers.
- * On the device a column is len[c] (u8), its top interval top[c] (u32: z1 | material << 16 |
- * flags << 24) with the bottom height topz0[c] (u16), and the rest of the stack plane-major,
- * rec[k*N + c] (u32), so that a wavefront touching the tops -- or interval k -- of
- * neighbouring columns reads contiguous bytes.
+ * On the device a column is its top interval top[c] (u32: z1 | material << 16 | flags << 24)
+ * and, plane-major, the intervals below it rec[p*N + c] (u32) chained through link[c] / prv[p*N + c]
+ * (u8 plane indices), so that a wavefront touching the tops -- or the intervals one process step
+ * laid down -- of neighbouring columns reads contiguous bytes; a layer's bottom is the top of
+ * the interval below it.
  * cg_download / cg_upload convert to and from the reference's host layout
  *     mat[c*Lmax + k],  zpair[2*(c*Lmax + k) + {0,1}],  len[c]
  * (reference: template/script_columngrid.js:84-86, 111-112).

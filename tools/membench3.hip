@@ -1,5 +1,6 @@
 // Micro-benchmark 3: the access mix of an "append" in the split column form, without the arithmetic:
-// per 4 columns R len (4 B) + top (16 B); W plane (16 B) + top (16 B) + topz0 (8 B) + len (4 B).
+// per 4 columns R len (4 B) + top (16 B); W plane (16 B) + top (16 B) + topz0 (8 B) + len (4 B)
+// (the access mix of an append in an earlier layout that kept the top's bottom and len as streams).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -1,4 +1,5 @@
-// Micro-benchmark 4: stream layouts for an "append" in the chained form (dense plane per step).
+// Micro-benchmark 4: stream layouts for an "append" in the chained form (dense plane per step), as
+// the layout stood when the top's bottom (topz0) and len were still streams of their own.
 //  A: separate small arrays  R len1 link1 top4 | W rec4 prv1 topz0_2 len1 link1 top4          (19 B/col, 9 streams)
 //  B: len+link packed u16    R ll2 top4        | W rec4 prv1 topz0_2 ll2 top4                  (19 B/col, 7 streams)
 //  C: aux u32 (z0|link|len)  R aux4 top4       | W rec4 prv1 aux4 top4                         (21 B/col, 6 streams)
