@@ -28,7 +28,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=16384, help="columns per side per GPU (default 16384)")
+    ap.add_argument("--n", "--size", type=int, default=16384, help="columns per side per GPU (default 16384)")
     ap.add_argument("--flow", default="c4", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--cpu-n", type=int, default=2048, help="grid side of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -114,11 +114,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    if os.environ.get("BENCH_ONE_GPU"):      # rehearsal of the N > 1 path on a one-GPU box (use with BENCH_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")          # nccl = RCCL; it wants one GPU per rank
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     nxl = ny = args.n
     nxg = nxl * world
