@@ -58,6 +58,26 @@ def label(k):
     return "k_vertical_g4<%s>" % ("etch" if args[0] == "true" else "deposit")
 
 
+# launch durations grouped the way bench.py groups them (its roofline.ms_avg is the average over the
+# timed launches of one group; the instances that collect statistics run in the untimed pass only)
+grp = defaultdict(lambda: [0.0, 0])
+for f in find("trace/**/*kernel_stats.csv"):
+    for row in csv.DictReader(open(f)):
+        k = short(row["Name"])
+        lb = label(k)
+        m = re.match(r"k_(stencil_sym|vertical_g4)<(.*)>", k)
+        if not lb or not m:
+            continue
+        args = [a.strip() for a in m.group(2).split(",")]
+        stats = args[3] if m.group(1) == "stencil_sym" else args[1]
+        if stats == "true":
+            continue
+        grp[lb][0] += float(row["TotalDurationNs"]); grp[lb][1] += int(row["Calls"])
+if grp:
+    print("== launch durations by bench.py's kernel groups (instances without statistics, warm-up + timed steps)")
+    for lb, (ns, n) in sorted(grp.items()):
+        print("  %-28s launches %4d  avg %10.4f ms  total %10.3f ms" % (lb, n, ns / n / 1e6, ns / 1e6))
+
 tr = defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0, "nf": 0, "nw": 0})
 for k in agg:
     lb = label(k)
