@@ -82,6 +82,7 @@ ABI = {
     "cg_strip_finish": (_i, [_vp]),
     "cg_etch_wet": (_i, [_vp, _i, _d, _d]),
     "cg_etch_wet_step": (_i, [_vp, _i, _i, _i]),
+    "cg_etch_wet_step_slab": (_i, [_vp, _i, _i, _i, C.c_uint32, _i, _vp, _vp]),
     "cg_deposit_ald": (_i, [_vp, _i, _d, _d]),
     "cg_ald_collect_seeds": (_i, [_vp, _d, C.POINTER(C.c_uint64)]),
     "cg_ald_seed_info": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_uint64)]),
@@ -491,6 +492,14 @@ class ColumnGrid:
 
     def etch_wet_step(self, matId, dt_q, diagonal):
         self._chk(self.lib.cg_etch_wet_step(self.h, int(matId), int(dt_q), int(bool(diagonal))))
+
+    def etch_wet_step_slab(self, matId, dt_q, diagonal, hmax_q, planes, ghost_lower, ghost_upper):
+        """One etch_wet increment of a slab (no cavity pass): see cg_etch_wet_step_slab."""
+        self._chk(self.lib.cg_etch_wet_step_slab(self.h, int(matId), int(dt_q), int(bool(diagonal)), int(hmax_q), int(planes),
+                                                 ghost_lower or None, ghost_upper or None))
+
+    def release_scratch(self):
+        self._chk(self.lib.cg_release_scratch(self.h))
 
     def slider_sizes(self):
         """(ALD anchors, wet-etch anchors, seeds held) -- what the reference keeps in sliderCache."""

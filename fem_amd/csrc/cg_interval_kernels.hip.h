@@ -65,14 +65,14 @@ __device__ __forceinline__ void copy_column(const GridView& s, const GridView& d
 // ------------------------------------------------------------------------------------------
 // etch_wet: one increment (stepOnce, script_columngrid3.js:250-268, without identify_cavity)
 // ------------------------------------------------------------------------------------------
-// Air runs of column n inside [0, Hq): everything that is not covered by a layer of material
-// >= 2 (cg3:12-36).  f(a, b) is called for each maximal run, bottom to top.
+// Air runs of a column inside [0, Hq): everything that is not covered by a layer of material
+// >= 2 (cg3:12-36).  f(a, b) is called for each maximal run, bottom to top.  The column is given
+// as a ColRef, so that it may be a ghost column of the neighbouring slab.
 template <class F>
-__device__ __forceinline__ void for_each_air_q(const GridView& g, size_t n, unsigned Hq, F&& f) {
-    const int l = g.len[n];
+__device__ __forceinline__ void for_each_air_q(const ColRef& n, unsigned Hq, F&& f) {
     unsigned prev = 0; bool open = false; unsigned a = 0;
-    for (int k = 0; k < l; k++) {
-        const uint32_t r = g.rec[(size_t)k * g.N + n];
+    for (int k = 0; k < n.len; k++) {
+        const uint32_t r = n.rec[(size_t)k * n.stride];
         const unsigned z1 = rec_z1(r);
         if (z1 <= prev) continue;                              // zero-thickness entries are not segments (cg2:983)
         const bool occ = !rec_hole(r) && rec_mat(r) >= 2;
@@ -84,15 +84,16 @@ __device__ __forceinline__ void for_each_air_q(const GridView& g, size_t n, unsi
     if (Hq > a) f(a, Hq);
 }
 
-// Removal intervals thrown at column (i, j) by the air of its neighbours (cg3:91-155).
+// Removal intervals thrown at column (i, j) by the air of its neighbours (cg3:91-155); beyond the
+// domain there is no neighbour (a slab edge inside the domain has ghost columns).
 template <class F>
-__device__ __forceinline__ void for_each_lateral_cut(const GridView& g, int i, int j, unsigned Hq, int d, bool diag, F&& f) {
+__device__ __forceinline__ void for_each_lateral_cut(const GridView& g, const Ghost& gh, int i, int j, unsigned Hq, int d, bool diag, F&& f) {
     const int di4[4] = {1, -1, 0, 0}, dj4[4] = {0, 0, 1, -1};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const int ni = i + di4[q], nj = j + dj4[q];
-        if (ni < 0 || nj < 0 || ni >= g.nx || nj >= g.ny) continue;
-        for_each_air_q(g, (size_t)ni * g.ny + nj, Hq, [&](unsigned a, unsigned b) {
+        const ColRef n = column_ref(g, gh, i + di4[q], j + dj4[q]);
+        if (!n.ok) continue;
+        for_each_air_q(n, Hq, [&](unsigned a, unsigned b) {
             const int q0 = max(0, (int)a - d), q1 = min((int)Hq, (int)b + d);
             if (q1 > q0) f(q0, q1);
         });
@@ -101,9 +102,9 @@ __device__ __forceinline__ void for_each_lateral_cut(const GridView& g, int i, i
         const int di8[4] = {1, 1, -1, -1}, dj8[4] = {1, -1, 1, -1};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int ni = i + di8[q], nj = j + dj8[q];
-            if (ni < 0 || nj < 0 || ni >= g.nx || nj >= g.ny) continue;
-            for_each_air_q(g, (size_t)ni * g.ny + nj, Hq, [&](unsigned a, unsigned b) {
+            const ColRef n = column_ref(g, gh, i + di8[q], j + dj8[q]);
+            if (!n.ok) continue;
+            for_each_air_q(n, Hq, [&](unsigned a, unsigned b) {
                 int q0 = (int)a + d, q1 = (int)b - d;
                 if (q1 <= q0) return;
                 q0 = max(q0, 0); q1 = min(q1, (int)Hq);
@@ -125,7 +126,7 @@ struct WetOut {                                                // merge of touch
     }
 };
 
-__global__ __launch_bounds__(256) void k_wet_step(GridView s, GridView d, int matId, int dtQ, int dtQDiag, int diag, unsigned Hq,
+__global__ __launch_bounds__(256) void k_wet_step(GridView s, Ghost gh, GridView d, int matId, int dtQ, int dtQDiag, int diag, unsigned Hq,
                                                   int* __restrict__ flags) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < s.N; c += stride) {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void k_wet_step(GridView s, GridView d, int ma
             }
             if (seg_below && wet_target(matId, below_m)) any = true;
         }
-        if (!any) for_each_lateral_cut(s, i, j, Hq, dtQDiag, diag != 0, [&](int, int) { any = true; });
+        if (!any) for_each_lateral_cut(s, gh, i, j, Hq, dtQDiag, diag != 0, [&](int, int) { any = true; });
         if (!any) { copy_column(s, d, c, flags); continue; }
 
         WetOut out(d, c);
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void k_wet_step(GridView s, GridView d, int ma
                     else if (a < nxt) nxt = a;
                 };
                 see(vt0, vt1); see(vb0, vb1);
-                for_each_lateral_cut(s, i, j, Hq, dtQDiag, diag != 0, see);
+                for_each_lateral_cut(s, gh, i, j, Hq, dtQDiag, diag != 0, see);
                 if (cover > cur) { cur = cover; continue; }
                 out.put((unsigned)cur, (unsigned)nxt, m);
                 cur = nxt;

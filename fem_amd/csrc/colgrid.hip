@@ -1267,26 +1267,40 @@ int cg_identify_cavity(cg_grid* g) {
 }
 
 // ---- etch_wet (script_columngrid2.js:893 - script_columngrid3.js:308) --------------------------
+static int wet_step_launch(cg_grid* g, int mat, int dt_q, int use_diagonal, unsigned Hq, const Ghost& gh) {
+    const int dt_diag = std::max(1, (int)std::floor(dt_q * 0.7071067811865476));                 // cg3:92
+    ProfScope ps(g, CG_K_OTHER);
+    return run_out_of_place(g, 0, "etch_wet", [&](GridView dst) {
+        hipLaunchKernelGGL(k_wet_step, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), gh, dst, mat, dt_q, dt_diag,
+                           use_diagonal ? 1 : 0, Hq, g->d_flags);
+    });
+}
+
 int cg_etch_wet_step(cg_grid* g, int mat, int dt_q, int use_diagonal) {
     NEED(g);
-    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "etch_wet on a slab of a decomposed domain is not built yet");
+    if (g->nx != g->nx_global)
+        return fail(g, CG_ERR_UNSUPPORTED, "etch_wet on a slab needs its neighbours' boundary rows and the whole domain's height: use cg_etch_wet_step_slab");
     if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
     if (dt_q < 1) return fail(g, CG_ERR_ARG, "etch_wet increment of %d height steps", dt_q);
     g->pend.active = false;
     unsigned qtop = 0;
     int rc = ensure_whole(g); if (rc) return rc;
     rc = refresh_len_bound(g, &qtop); if (rc) return rc;
-    const unsigned Hq = std::max(qtop, 1u);                                                      // cg3:8
-    const int dt_diag = std::max(1, (int)std::floor(dt_q * 0.7071067811865476));                 // cg3:92
-    {
-        ProfScope ps(g, CG_K_OTHER);
-        rc = run_out_of_place(g, 0, "etch_wet", [&](GridView dst) {
-            hipLaunchKernelGGL(k_wet_step, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), dst, mat, dt_q, dt_diag,
-                               use_diagonal ? 1 : 0, Hq, g->d_flags);
-        });
-        if (rc) return rc;
-    }
+    const Ghost none = make_ghost(g, 0, nullptr, nullptr);
+    rc = wet_step_launch(g, mat, dt_q, use_diagonal, std::max(qtop, 1u), none); if (rc) return rc;      // cg3:8
     return cg_identify_cavity(g);                                                                // cg3:267
+}
+
+int cg_etch_wet_step_slab(cg_grid* g, int mat, int dt_q, int use_diagonal, uint32_t hmax_q, int planes,
+                          const void* ghost_lower, const void* ghost_upper) {
+    NEED(g);
+    if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
+    if (dt_q < 1) return fail(g, CG_ERR_ARG, "etch_wet increment of %d height steps", dt_q);
+    if (planes < 0 || planes > 256) return fail(g, CG_ERR_ARG, "bad ghost plane count %d", planes);
+    g->pend.active = false;
+    int rc = ensure_whole(g); if (rc) return rc;
+    const Ghost gh = make_ghost(g, planes, ghost_lower, ghost_upper);
+    return wet_step_launch(g, mat, dt_q, use_diagonal, std::max((unsigned)hmax_q, 1u), gh);
 }
 
 int cg_etch_wet(cg_grid* g, int mat, double total_thickness, double dt) {

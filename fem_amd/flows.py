@@ -170,6 +170,18 @@ def flow_cw():
     ]
 
 
+def flow_cwet():
+    """Not a benchmark configuration: WETETCH undercuts between lateral steps, STRIP and CMP, for the
+    parity tests of the slab driver (which runs etch_wet across slab edges, deposit_ALD not)."""
+    return [
+        _s("SUBSTR", None, SI, 30), _s("DEPO", None, OX, 8), _s("DEPO", None, NIT, 12),
+        _s("ETCH", "M", ALL, 26), _s("WETETCH", None, OX, 5), _s("DEPO", None, M6, 3, 1.0),
+        _s("ETCH", "Mc", ALL, 14), _s("WETETCH", None, ALL, 2.5), _s("DEPO", None, M7, 6, 1.0),
+        _s("CMP", None, 0, 7), _s("STRIP", None, M6, 1), _s("DEPO", None, OX, 6, 1.0),
+        _s("WETETCH", None, M7, 3.3), _s("ETCH", "Mshift", ALL, 9, 0.6), _s("WETETCH", None, NIT, 1.7),
+    ]
+
+
 def flow_cs():
     """Not a benchmark configuration: gaps, enclosed cavities, STRIP and CMP with and without a
     stopper, for the parity tests of the slab driver."""
@@ -181,7 +193,7 @@ def flow_cs():
     ]
 
 
-FLOWS = {"c1": flow_c1, "c2": flow_c2, "c3": flow_c3, "c4": flow_c4, "c5": flow_c5, "cw": flow_cw, "cs": flow_cs}
+FLOWS = {"c1": flow_c1, "c2": flow_c2, "c3": flow_c3, "c4": flow_c4, "c5": flow_c5, "cw": flow_cw, "cs": flow_cs, "cwet": flow_cwet}
 
 
 def apply_step(grid, step, masks):

@@ -132,11 +132,7 @@ class SlabGrid:
         g = self.grid
         self._gaps_anywhere = None
         planes = self._reduce_max([g.cavity_state()[2]])[0]
-        nbytes = g.ghost_bytes(planes)
-        if getattr(self, "_ghost", None) is None or self._ghost[0].numel() < nbytes:
-            self._ghost = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(4)]
-        s_lo, s_up, r_lo, r_up = [t.data_ptr() for t in self._ghost]
-        lo, up = (r_lo if self.has_lower else 0), (r_up if self.has_upper else 0)
+        nbytes, s_lo, s_up, lo, up = self._ghost_buffers(planes)
         g.ghost_pack(planes, s_lo, s_up); g.sync(); self._swap_ghosts(nbytes)
         g.strip_seed(matId, planes, lo, up)
         g.ghost_pack(planes, s_lo, s_up); g.sync(); self._swap_ghosts(nbytes)
@@ -146,6 +142,47 @@ class SlabGrid:
                 break
             g.ghost_pack(planes, s_lo, s_up); g.sync(); self._swap_ghosts(nbytes)
         g.strip_finish()
+
+    def _ghost_buffers(self, planes):
+        """(bytes per message, send lower, send upper, received lower or 0, received upper or 0)."""
+        nbytes = self.grid.ghost_bytes(planes)
+        if getattr(self, "_ghost", None) is None or self._ghost[0].numel() < nbytes:
+            self._ghost = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(4)]
+        s_lo, s_up, r_lo, r_up = [t.data_ptr() for t in self._ghost]
+        return nbytes, s_lo, s_up, (r_lo if self.has_lower else 0), (r_up if self.has_upper else 0)
+
+    def etch_wet(self, matId, totalThk, dt=None):
+        """etch_wet(matId, totalThk, {dt}) (script_columngrid2.js:893 - script_columngrid3.js:308) over all
+        slabs, without the slider cache: per increment one ghost row per side is swapped (a cut reaches
+        one column sideways), the increment runs on every slab against the whole domain's height, and
+        the cavity pass follows over all slabs."""
+        if self.world == 1:
+            return self.grid.etch_wet(matId, totalThk, dt=dt)
+        g = self.grid
+        T = 0.0 if totalThk != totalThk else max(0.0, float(totalThk))                       # cg2:894-895
+        if T <= 0:
+            return
+        base_dt = min(self.dx, self.dy) if dt is None else float(dt)                          # cg2:905
+        if not base_dt > 1e-6:
+            base_dt = 1e-6
+        zs = g.zScale
+        R, t = 0.0, 0.0
+        while t < T - 1e-9:                                                                   # cg3:286-306
+            R += 0.7071067811865476
+            diag = False
+            if R > 1:
+                R -= 1; diag = True
+            dt_q = max(1, int(g._js_round(min(base_dt, T - t) / zs)))
+            _, _, max_len, top_q = g.cavity_state()
+            planes, hmax_q = self._reduce_max([max_len, top_q])
+            nbytes, s_lo, s_up, lo, up = self._ghost_buffers(planes)
+            g.ghost_pack(planes, s_lo, s_up); g.sync(); self._swap_ghosts(nbytes)
+            g.etch_wet_step_slab(matId, dt_q, diag, hmax_q, planes, lo, up)
+            self._gaps_anywhere = None
+            self.identify_cavity()                                                            # cg3:267
+            t += dt_q * zs
+        self.identify_cavity()                                                                # cg3:307
+        g.release_scratch()
 
     def identify_cavity(self):
         """identify_cavity() (script_columngrid2.js:9-83) over all slabs."""

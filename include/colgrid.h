@@ -197,6 +197,14 @@ int cg_etch_wet(cg_grid* g, int mat, double total_thickness, double dt);
  * cg_snapshot_save/load and cg_release_scratch. */
 int cg_etch_wet_step(cg_grid* g, int mat, int dt_q, int use_diagonal);
 
+/* The same increment on a slab of a decomposed domain, WITHOUT the cavity pass: the caller has
+ * packed and swapped one ghost row per side (cg_ghost_pack with `planes` = the largest column
+ * of any slab), passes the whole domain's quantised maximum height, and afterwards runs the
+ * cavity pass over all slabs (cg_cavity_state / cg_cavity_fill / cg_strip_*).  Null ghost
+ * pointers = the domain ends there.  No counterpart in the reference (it is single-threaded). */
+int cg_etch_wet_step_slab(cg_grid* g, int mat, int dt_q, int use_diagonal, uint32_t hmax_q, int planes,
+                          const void* ghost_lower, const void* ghost_upper);
+
 /* deposit_ALD(matId, totalThk, {dt}) without the slider cache (cg2:111-868): seeds on every
  * exposed face, a coat of thickness t grown from them for t = dt, 2dt, ... < total (only the
  * cavities it pinches off are kept), then the final coat and identify_cavity.
