@@ -127,7 +127,7 @@ def _random_mask_data(rng, L, nshapes):
     return {"objects": objs}
 
 
-@pytest.mark.parametrize("nx,ny,seed", [(192, 320, 1), (333, 257, 2), (512, 512, 3)])
+@pytest.mark.parametrize("nx,ny,seed", [(192, 320, 1), (333, 257, 2), (512, 512, 3), (100, 90, 4)])   # the last: 4-column vertical kernels, one-column lateral ones
 def test_random_flow_vs_oracle(nx, ny, seed):
     """A seeded multi-step flow with every supported step kind on grids the oracle does in seconds."""
     fem = _engine()
@@ -165,7 +165,7 @@ def test_random_flow_vs_oracle(nx, ny, seed):
     g.close()
 
 
-@pytest.mark.parametrize("nx,ny,seed", [(160, 224, 11), (301, 128, 12)])
+@pytest.mark.parametrize("nx,ny,seed", [(160, 224, 11), (301, 128, 12), (100, 90, 13)])
 def test_random_flow_with_strip_cmp_cavity_vs_oracle(nx, ny, seed):
     """Flows that create buried gaps and enclosed cavities: strip_connected, identify_cavity (through
     conformal deposits and cmp) and cmp with and without a stopper, against the oracle step by step."""
