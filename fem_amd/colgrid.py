@@ -90,6 +90,7 @@ ABI = {
     "cg_ald_increment": (_i, [_vp, _i, _d]),
     "cg_ald_coat": (_i, [_vp, _i, _d]),
     "cg_release_scratch": (_i, [_vp]),
+    "cg_set_plane_budget": (_i, [_vp, _i]),
     "cg_add_layer": (_i, [_vp, _i, _i, _i, _d, _d]),
     "cg_remove_top_layer": (_i, [_vp, _i, _i]),
     "cg_max_height": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_uint32)]),
@@ -500,6 +501,10 @@ class ColumnGrid:
 
     def release_scratch(self):
         self._chk(self.lib.cg_release_scratch(self.h))
+
+    def set_plane_budget(self, max_planes):
+        """Cap on the planes the handle maps before it compacts its columns instead (see cg_set_plane_budget)."""
+        self._chk(self.lib.cg_set_plane_budget(self.h, int(max_planes)))
 
     def slider_sizes(self):
         """(ALD anchors, wet-etch anchors, seeds held) -- what the reference keeps in sliderCache."""

@@ -54,9 +54,18 @@ struct ConfKernel {
     Tap* d_taps64_sym = nullptr; int ntaps64_sym = 0;
 };
 
+// A device buffer that grows and shrinks in place: a reserved address range of which a prefix is
+// backed by physical chunks (HIP virtual memory management).  Growing maps one more chunk behind
+// the data -- nothing is copied, pointers stay valid -- and shrinking unmaps whole chunks from the end.
+struct Elastic {
+    char* base = nullptr; size_t reserved = 0, mapped = 0, unit = 0;      // unit: bytes of every chunk
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+};
+
 struct Snapshot {
     uint8_t* len = nullptr; uint32_t* rec = nullptr; uint32_t* top = nullptr;
     uint8_t* link = nullptr; uint8_t* prv = nullptr; int nextp = 0;
+    int planes = 0;                                       // planes copied (the ones in use when it was taken)
     bool split = true, len_valid = true;
     int lmax = 0; int lmax_vis = 0; int len_bound = 0; bool has_gaps = false, has_cavity = false;
 };
@@ -113,6 +122,9 @@ struct cg_grid {
     bool halo_external = false;
     // etch_wet / deposit_ALD write a second set of planes (ALD's cavity merge a third) and swap
     uint8_t* alt_len[2] = {nullptr, nullptr}; uint32_t* alt_rec[2] = {nullptr, nullptr}; int alt_lmax[2] = {0, 0};
+    // rec (the grid's and the two spare sets') and prv live in elastic buffers; rec / prv / alt_rec are their bases
+    Elastic rec_el, prv_el, alt_el[2];
+    int plane_budget = 256;                                // most planes the handle may map before it compacts instead (cg_set_plane_budget)
     // deposit_ALD: seeds of the exposed faces (plane-major like the grid), their bounding box, the tap table
     uint16_t* seed_n = nullptr; uint2* seed = nullptr; int seed_planes = 0; bool has_seeds = false;
     int seed_bbox[4] = {0, -1, 0, -1}; uint64_t seed_total = 0;
@@ -186,25 +198,90 @@ unsigned blocks_for(size_t n) {
     return (unsigned)std::min<size_t>(std::max<size_t>(b, 1), 256 * 16);
 }
 
+// ---- elastic buffers ---------------------------------------------------------------------------
+int el_reserve(cg_grid* g, Elastic& e, size_t bytes, size_t unit_bytes) {
+    if (e.base) return CG_OK;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = g->device;
+    size_t gran = 0;
+    HIPCHK(g, hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    gran = std::max<size_t>(gran, (size_t)2 << 20);
+    // All chunks of one range have the same size: with chunks of different sizes in one range
+    // hipMemSetAccess refused some of them ("invalid argument", ROCm 7.2), with equal ones never.
+    e.unit = (std::max<size_t>(unit_bytes, 1) + gran - 1) / gran * gran;
+    e.reserved = (std::max<size_t>(bytes, 1) + e.unit - 1) / e.unit * e.unit;
+    void* p = nullptr;
+    HIPCHK(g, hipMemAddressReserve(&p, e.reserved, 0, nullptr, 0));
+    e.base = (char*)p; e.mapped = 0;
+    return CG_OK;
+}
+// Make at least `bytes` of the buffer usable (growth), or give back the chunks beyond them (shrink).
+int el_resize(cg_grid* g, Elastic& e, size_t bytes) {
+    const size_t want = (bytes + e.unit - 1) / e.unit * e.unit;
+    if (want > e.reserved) return fail(g, CG_ERR_NOMEM, "elastic buffer: %zu bytes asked, %zu reserved", want, e.reserved);
+    while (e.mapped < want) {
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = g->device;
+        hipMemGenericAllocationHandle_t h;
+        hipError_t er = hipMemCreate(&h, e.unit, &prop, 0);
+        if (er != hipSuccess) { (void)hipGetLastError(); return fail(g, CG_ERR_NOMEM, "no device memory for %zu more bytes of planes (%s)", e.unit, hipGetErrorString(er)); }
+        er = hipMemMap(e.base + e.mapped, e.unit, 0, h, 0);
+        if (er != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return fail(g, CG_ERR_HIP, "hipMemMap: %s", hipGetErrorString(er)); }
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice; acc.location.id = g->device; acc.flags = hipMemAccessFlagsProtReadWrite;
+        er = hipMemSetAccess(e.base + e.mapped, e.unit, &acc, 1);
+        if (er != hipSuccess) {
+            (void)hipGetLastError(); (void)hipMemUnmap(e.base + e.mapped, e.unit); (void)hipMemRelease(h);
+            return fail(g, CG_ERR_HIP, "hipMemSetAccess(base %p + %zu, %zu bytes): %s", (void*)e.base, e.mapped, e.unit, hipGetErrorString(er));
+        }
+        e.chunks.push_back(h); e.mapped += e.unit;
+    }
+    bool synced = false;
+    while (e.mapped >= want + e.unit) {
+        if (!synced) { HIPCHK(g, hipStreamSynchronize(g->stream)); synced = true; }
+        const hipMemGenericAllocationHandle_t h = e.chunks.back(); e.chunks.pop_back();
+        e.mapped -= e.unit;
+        HIPCHK(g, hipMemUnmap(e.base + e.mapped, e.unit));
+        HIPCHK(g, hipMemRelease(h));
+    }
+    return CG_OK;
+}
+void el_free(Elastic& e) {
+    while (!e.chunks.empty()) {
+        const hipMemGenericAllocationHandle_t h = e.chunks.back(); e.chunks.pop_back();
+        e.mapped -= e.unit;
+        (void)hipMemUnmap(e.base + e.mapped, e.unit); (void)hipMemRelease(h);
+    }
+    if (e.base) (void)hipMemAddressFree(e.base, e.reserved);
+    e.base = nullptr; e.reserved = 0; e.mapped = 0;
+}
+
+constexpr int MAX_PLANES = 256;
+
 void free_planes(cg_grid* g) {
     if (g->len) (void)hipFree(g->len);
-    if (g->rec) (void)hipFree(g->rec);
     if (g->top) (void)hipFree(g->top);
     if (g->top_alt) (void)hipFree(g->top_alt);
     if (g->link) (void)hipFree(g->link);
-    if (g->prv) (void)hipFree(g->prv);
+    el_free(g->rec_el); el_free(g->prv_el);
     g->len = nullptr; g->rec = nullptr; g->top = nullptr; g->top_alt = nullptr; g->link = nullptr; g->prv = nullptr;
+    g->lmax = 0;
 }
 
+// Planes for `lmax` intervals per column.  The column streams are allocated once; the planes are
+// address ranges for MAX_PLANES planes of which the first lmax are backed (see Elastic).
 int alloc_planes(cg_grid* g, int lmax) {
-    free_planes(g);
-    size_t S = g->N * (size_t)lmax;
-    HIPCHK(g, hipMalloc(&g->len, std::max<size_t>(g->N, 4)));
-    HIPCHK(g, hipMalloc(&g->rec, std::max<size_t>(4 * S, 4)));
-    HIPCHK(g, hipMalloc(&g->top, std::max<size_t>(4 * g->N, 16)));
-    HIPCHK(g, hipMalloc(&g->top_alt, std::max<size_t>(4 * g->N, 16)));
-    HIPCHK(g, hipMalloc(&g->link, std::max<size_t>(g->N, 16)));
-    HIPCHK(g, hipMalloc(&g->prv, std::max<size_t>(S, 16)));
+    if (!g->len) {
+        HIPCHK(g, hipMalloc(&g->len, std::max<size_t>(g->N, 4)));
+        HIPCHK(g, hipMalloc(&g->top, std::max<size_t>(4 * g->N, 16)));
+        HIPCHK(g, hipMalloc(&g->top_alt, std::max<size_t>(4 * g->N, 16)));
+        HIPCHK(g, hipMalloc(&g->link, std::max<size_t>(g->N, 16)));
+    }
+    int rc = el_reserve(g, g->rec_el, 4 * g->N * (size_t)MAX_PLANES, 4 * g->N * 16); if (rc) return rc;        // chunks of 16 planes
+    rc = el_reserve(g, g->prv_el, g->N * (size_t)MAX_PLANES, g->N * 16); if (rc) return rc;
+    rc = el_resize(g, g->rec_el, 4 * g->N * (size_t)lmax); if (rc) return rc;
+    rc = el_resize(g, g->prv_el, g->N * (size_t)lmax); if (rc) return rc;
+    g->rec = (uint32_t*)g->rec_el.base; g->prv = (uint8_t*)g->prv_el.base;
     g->lmax = lmax;
     return CG_OK;
 }
@@ -225,6 +302,7 @@ int zero_planes(cg_grid* g, bool all = true) {
 // The kernels of the vertical and lateral steps work on the split form, the ones that
 // restructure whole columns (strip, cavity, CMP, wet etch, ALD, upload) on whole stacks.
 int refresh_len_bound(cg_grid* g, unsigned* topq_out);
+int trim_planes(cg_grid* g);
 // The vertical and lateral kernels that own 4 columns per thread work from the chains alone and
 // leave len[] behind; whatever reads len[] of a grid in split form calls this first.
 int ensure_len(cg_grid* g) {
@@ -255,26 +333,38 @@ int ensure_whole(cg_grid* g) {
     return CG_OK;
 }
 
-// _expandBuffers (script_columngrid.js:129-168): Lmax += 16.  Plane-major storage makes the old
-// contents a prefix of the new allocation: one copy per array, no re-striding.
+// More planes (the device side of _expandBuffers, script_columngrid.js:129-168; the Lmax a caller
+// sees is tracked apart, see sync_vis).  Plane-major storage makes the old contents a prefix of
+// the new extent, and the buffers grow in place: nothing is copied.
 int grow_planes(cg_grid* g, int add = 16) {
-    const int newL = std::min(256, g->lmax + add);
+    const int newL = std::min(MAX_PLANES, g->lmax + add);
     if (newL == g->lmax) return CG_OK;
-    size_t So = g->N * (size_t)g->lmax, Sn = g->N * (size_t)newL;
-    uint32_t* nr = nullptr;
-    HIPCHK(g, hipMalloc(&nr, 4 * Sn));
-    HIPCHK(g, hipMemcpyAsync(nr, g->rec, 4 * So, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemsetAsync(nr + So, 0, 4 * (Sn - So), g->stream));
-    HIPCHK(g, hipStreamSynchronize(g->stream));
-    (void)hipFree(g->rec);
-    g->rec = nr;
-    uint8_t* np = nullptr;
-    HIPCHK(g, hipMalloc(&np, Sn));
-    HIPCHK(g, hipMemcpyAsync(np, g->prv, So, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipStreamSynchronize(g->stream));
-    (void)hipFree(g->prv);
-    g->prv = np; g->lmax = newL;
+    int rc = el_resize(g, g->rec_el, 4 * g->N * (size_t)newL); if (rc) return rc;
+    rc = el_resize(g, g->prv_el, g->N * (size_t)newL); if (rc) return rc;
+    g->lmax = newL;
     return CG_OK;
+}
+
+// Give back the planes no column reaches (whole form only): scratch sets and snapshots are sized
+// by the planes in use, and a long run of deposits may have mapped many more than that.
+int trim_planes(cg_grid* g) {
+    if (g->split) return CG_OK;
+    int rc = refresh_len_bound(g, nullptr); if (rc) return rc;
+    const int want = std::max(std::min(g->lmax_vis, MAX_PLANES), (g->len_bound + 15) / 16 * 16);
+    if (want + 16 > g->lmax) return CG_OK;
+    rc = el_resize(g, g->rec_el, 4 * g->N * (size_t)want); if (rc) return rc;
+    rc = el_resize(g, g->prv_el, g->N * (size_t)want); if (rc) return rc;
+    g->lmax = want;
+    return CG_OK;
+}
+
+// Is there device memory for `add` more planes, with room left for a copy of the planes in use
+// (a snapshot, or the scratch set of etch_wet / deposit_ALD) and some slack?
+bool memory_allows_planes(cg_grid* g, int add) {
+    size_t fr = 0, to = 0;
+    if (hipMemGetInfo(&fr, &to) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const size_t plane = 5 * g->N;
+    return fr > plane * (size_t)add + plane * (size_t)std::max(g->len_bound, 16) + to / 16;
 }
 
 int read_flags(cg_grid* g, int out[4]) {
@@ -440,14 +530,22 @@ int ensure_stencil_scratch(cg_grid* g, int R, bool need_halo) {
 }
 
 // The plane a depositing launch pushes old tops into: every such launch gets a fresh one, so
-// its writes are dense whatever the column lengths.  When the planes run out the columns are
-// compacted (whole form and back: interval k in plane k), which frees every plane above max(len)-2.
+// its writes are dense whatever the column lengths.  When the planes run out, more are mapped
+// behind them as long as memory and the handle's budget allow (nothing moves); otherwise the
+// columns are compacted (whole form and back: interval k in plane k), which frees every plane
+// above max(len)-2 at the price of moving every interval.
 int take_append_plane(cg_grid* g, int* P) {
-    if (g->nextp >= std::min(g->lmax, 255)) {                  // (255 = LINK_NONE is never a link)
-        int rc = ensure_whole(g); if (rc) return rc;
-        rc = refresh_len_bound(g, nullptr); if (rc) return rc;
-        rc = ensure_split(g); if (rc) return rc;
-        if (g->nextp >= std::min(g->lmax, 255)) { rc = grow_planes(g); if (rc) return rc; }
+    const int cap = std::min(std::min(g->plane_budget, MAX_PLANES), 255);          // (255 = LINK_NONE is never a link)
+    if (g->nextp >= std::min(g->lmax, 255)) {
+        if (g->lmax + 16 <= cap && memory_allows_planes(g, 16)) {
+            int rc = grow_planes(g); if (rc) return rc;                          // in place, nothing moves
+        } else {
+            int rc = ensure_whole(g); if (rc) return rc;
+            rc = refresh_len_bound(g, nullptr); if (rc) return rc;
+            rc = ensure_split(g); if (rc) return rc;
+            if (g->nextp >= std::min(g->lmax, 255)) { rc = grow_planes(g); if (rc) return rc; }
+            if (g->nextp >= std::min(g->lmax, 255)) return fail(g, CG_ERR_UNSUPPORTED, "a column holds more than 255 intervals");
+        }
     }
     *P = g->nextp++;
     return CG_OK;
@@ -589,20 +687,20 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
 // ---- second / third set of planes for the out-of-place models ---------------------------------
 void free_alt(cg_grid* g, int which) {
     if (g->alt_len[which]) (void)hipFree(g->alt_len[which]);
-    if (g->alt_rec[which]) (void)hipFree(g->alt_rec[which]);
+    el_free(g->alt_el[which]);
     g->alt_len[which] = nullptr; g->alt_rec[which] = nullptr; g->alt_lmax[which] = 0;
 }
 
-// an all-empty set of planes as tall as the grid's
+// a spare set of planes as tall as the grid's (its contents are whatever the last user left)
 int ensure_alt(cg_grid* g, int which) {
     if (g->alt_rec[which] && g->alt_lmax[which] == g->lmax) return CG_OK;
-    HIPCHK(g, hipStreamSynchronize(g->stream));
-    free_alt(g, which);
-    const size_t S = g->N * (size_t)g->lmax;
-    HIPCHK(g, hipMalloc(&g->alt_len[which], std::max<size_t>(g->N, 4)));
-    HIPCHK(g, hipMalloc(&g->alt_rec[which], std::max<size_t>(4 * S, 4)));
-    HIPCHK(g, hipMemsetAsync(g->alt_len[which], 0, g->N, g->stream));
-    HIPCHK(g, hipMemsetAsync(g->alt_rec[which], 0, 4 * S, g->stream));
+    if (!g->alt_len[which]) {
+        HIPCHK(g, hipMalloc(&g->alt_len[which], std::max<size_t>(g->N, 4)));
+        HIPCHK(g, hipMemsetAsync(g->alt_len[which], 0, g->N, g->stream));
+    }
+    int rc = el_reserve(g, g->alt_el[which], 4 * g->N * (size_t)MAX_PLANES, 4 * g->N * 16); if (rc) return rc;
+    rc = el_resize(g, g->alt_el[which], 4 * g->N * (size_t)g->lmax); if (rc) return rc;
+    g->alt_rec[which] = (uint32_t*)g->alt_el[which].base;
     g->alt_lmax[which] = g->lmax;
     return CG_OK;
 }
@@ -615,6 +713,7 @@ GridView alt_view(const cg_grid* g, int which) {
 
 void swap_alt(cg_grid* g, int which) {
     std::swap(g->len, g->alt_len[which]); std::swap(g->rec, g->alt_rec[which]); std::swap(g->lmax, g->alt_lmax[which]);
+    std::swap(g->rec_el, g->alt_el[which]);
     g->split = false;                            // the out-of-place kernels write whole stacks
 }
 
@@ -622,6 +721,7 @@ void swap_alt(cg_grid* g, int which) {
 // fit, then make dst the grid (the old planes become the spare set).
 template <class Launch>
 int run_out_of_place(cg_grid* g, int which, const char* what, Launch launch) {
+    { int rc = trim_planes(g); if (rc) return rc; }        // the spare set is as tall as the grid: no taller than needed
     for (int attempt = 0; attempt < 17; attempt++) {
         int rc = ensure_alt(g, which); if (rc) return rc;
         HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
@@ -832,12 +932,16 @@ int cg_reset(cg_grid* g, int lmax_init) {
     if (lmax > 256) lmax = 256;
     g->pend.active = false;
     g->lmax_vis = lmax;
-    if (lmax != g->lmax) {
-        HIPCHK(g, hipStreamSynchronize(g->stream));
-        int rc = alloc_planes(g, lmax); if (rc) return rc;
-        return zero_planes(g, true);
-    }
-    return zero_planes(g, g->len_bound > g->lmax);
+    // the planes mapped so far stay (capacity, not state); more are mapped if the new Lmax asks for them
+    if (lmax > g->lmax) { int rc = grow_planes(g, lmax - g->lmax); if (rc) return rc; }
+    return zero_planes(g, true);
+}
+
+int cg_set_plane_budget(cg_grid* g, int max_planes) {
+    NEED(g);
+    if (max_planes < 1) return fail(g, CG_ERR_ARG, "plane budget %d", max_planes);
+    g->plane_budget = std::min(max_planes, MAX_PLANES);
+    return CG_OK;
 }
 
 int cg_clear(cg_grid* g) { NEED(g); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
@@ -1548,7 +1652,7 @@ int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8
     if (!mat || !zpair || !len || lmax < 1 || lmax > 256) return fail(g, CG_ERR_ARG, "bad upload arguments (lmax=%d)", lmax);
     g->pend.active = false;
     HIPCHK(g, hipStreamSynchronize(g->stream));
-    if (lmax != g->lmax) { int rc = alloc_planes(g, lmax); if (rc) return rc; }
+    if (lmax > g->lmax) { int rc = grow_planes(g, lmax - g->lmax); if (rc) return rc; }
     g->lmax_vis = lmax;
     g->split = false;                                       // the scatter kernel writes whole stacks
     const int L = lmax;
@@ -1585,15 +1689,19 @@ int cg_snapshot_save(cg_grid* g, int slot) {
     NEED(g);
     if (slot < 0) return fail(g, CG_ERR_ARG, "bad snapshot slot %d", slot);
     cg_snapshot_drop(g, slot);
-    Snapshot s; size_t S = g->N * (size_t)g->lmax;
+    // only the planes in use are copied: split form, the ones handed out so far; whole form, max(len)
+    if (!g->split) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; }
+    Snapshot s;
+    s.planes = std::min(g->lmax, g->split ? g->nextp : g->len_bound);
+    const size_t S = g->N * (size_t)s.planes;
     HIPCHK(g, hipMalloc(&s.len, std::max<size_t>(g->N, 4))); HIPCHK(g, hipMalloc(&s.rec, std::max<size_t>(4 * S, 4)));
     HIPCHK(g, hipMalloc(&s.top, std::max<size_t>(4 * g->N, 16)));
     HIPCHK(g, hipMalloc(&s.link, std::max<size_t>(g->N, 16))); HIPCHK(g, hipMalloc(&s.prv, std::max<size_t>(S, 16)));
     HIPCHK(g, hipMemcpyAsync(s.link, g->link, g->N, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(s.prv, g->prv, S, hipMemcpyDeviceToDevice, g->stream));
+    if (S) HIPCHK(g, hipMemcpyAsync(s.prv, g->prv, S, hipMemcpyDeviceToDevice, g->stream));
     s.nextp = g->nextp;
     HIPCHK(g, hipMemcpyAsync(s.len, g->len, g->N, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(s.rec, g->rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
+    if (S) HIPCHK(g, hipMemcpyAsync(s.rec, g->rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(s.top, g->top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
     s.split = g->split;
     s.len_valid = g->len_valid; s.lmax = g->lmax; s.lmax_vis = g->lmax_vis; s.len_bound = g->len_bound; s.has_gaps = g->has_gaps; s.has_cavity = g->has_cavity;
@@ -1607,13 +1715,13 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     if (it == g->snaps.end()) return fail(g, CG_ERR_ARG, "no snapshot in slot %d", slot);
     const Snapshot& s = it->second;
     g->pend.active = false;
-    if (s.lmax != g->lmax) { HIPCHK(g, hipStreamSynchronize(g->stream)); int rc = alloc_planes(g, s.lmax); if (rc) return rc; }
-    size_t S = g->N * (size_t)g->lmax;
+    if (s.planes > g->lmax) { int rc = grow_planes(g, (s.planes - g->lmax + 15) / 16 * 16); if (rc) return rc; }
+    const size_t S = g->N * (size_t)s.planes;
     HIPCHK(g, hipMemcpyAsync(g->len, s.len, g->N, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(g->rec, s.rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
+    if (S) HIPCHK(g, hipMemcpyAsync(g->rec, s.rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->top, s.top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->link, s.link, g->N, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(g->prv, s.prv, S, hipMemcpyDeviceToDevice, g->stream));
+    if (S) HIPCHK(g, hipMemcpyAsync(g->prv, s.prv, S, hipMemcpyDeviceToDevice, g->stream));
     g->nextp = s.nextp;
     g->split = s.split;
     g->len_bound = s.len_bound; g->has_gaps = s.has_gaps; g->has_cavity = s.has_cavity;

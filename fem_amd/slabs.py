@@ -26,31 +26,46 @@ STENCIL_DEPOSIT, STENCIL_ETCH = 0, 1
 
 
 class TorchComm:
-    """Neighbour swaps and small all-reduces over torch.distributed (backend nccl = RCCL, or gloo)."""
+    """Neighbour swaps and small all-reduces over torch.distributed (backend nccl = RCCL, or gloo).
+
+    RCCL moves device buffers directly.  gloo is a host-memory transport: device buffers are staged
+    through host tensors here (its own handling of device tensors hung now and then in an all-reduce
+    with two ranks on one GPU), which is also what the CPU tests exercise."""
 
     def __init__(self, rank, world, device, group=None):
         self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.stage = dist.get_backend(group) == "gloo" and torch.device(device).type != "cpu"
 
     def start_swap(self, send_lower, send_upper, recv_lower, recv_upper):
         """send_lower -> rank-1 (arrives as its recv_upper), send_upper -> rank+1 (its recv_lower).
         Returns what finish_swap waits for; with nccl the transfers run on RCCL's own stream, after
         the work already queued on the current one."""
+        back = []
+        if self.stage:
+            torch.cuda.current_stream().synchronize()
+            host = [send_lower.cpu(), send_upper.cpu(), torch.empty_like(recv_lower, device="cpu"), torch.empty_like(recv_upper, device="cpu")]
+            back = [(recv_lower, host[2], self.rank > 0), (recv_upper, host[3], self.rank < self.world - 1)]
+            send_lower, send_upper, recv_lower, recv_upper = host
         ops = []
         if self.rank > 0:
             ops += [dist.P2POp(dist.isend, send_lower, self.rank - 1, self.group), dist.P2POp(dist.irecv, recv_lower, self.rank - 1, self.group)]
         if self.rank < self.world - 1:
             ops += [dist.P2POp(dist.isend, send_upper, self.rank + 1, self.group), dist.P2POp(dist.irecv, recv_upper, self.rank + 1, self.group)]
-        return dist.batch_isend_irecv(ops) if ops else []
+        return (dist.batch_isend_irecv(ops) if ops else []), back
 
-    def finish_swap(self, reqs):
+    def finish_swap(self, pending):
+        reqs, back = pending
         for req in reqs:
             req.wait()
+        for dev_t, host_t, used in back:
+            if used:
+                dev_t.copy_(host_t)
 
     def swap(self, send_lower, send_upper, recv_lower, recv_upper):
         self.finish_swap(self.start_swap(send_lower, send_upper, recv_lower, recv_upper))
 
     def reduce(self, values, op="max", dtype=torch.int64):
-        t = torch.tensor(list(values), dtype=dtype, device=self.device)
+        t = torch.tensor(list(values), dtype=dtype, device="cpu" if self.stage else self.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.group)
         return t.tolist()
 
@@ -90,6 +105,8 @@ class SlabGrid:
         interior = getattr(self.grid, "stencil_interior", None)
         if interior is None or not hasattr(self.comm, "start_swap"):
             return self.comm.swap(*bufs)
+        if getattr(self.comm, "stage", False):
+            self.grid.sync()                     # the rows are copied to the host by torch, not on the grid's stream
         reqs = self.comm.start_swap(*bufs)
         interior()
         self.comm.finish_swap(reqs)

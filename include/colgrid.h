@@ -104,6 +104,13 @@ int cg_destroy(cg_grid* g);
  * layers (pass 0 to keep the current Lmax) and empty every column. */
 int cg_reset(cg_grid* g, int lmax_init);
 
+/* Most planes (intervals per column kept below the tops) the handle may back with memory
+ * before it compacts the columns instead of mapping more.  Every depositing step takes a
+ * plane; by default more are mapped in place while device memory allows (room for one copy
+ * of the planes in use is always left), which keeps long flows free of compaction passes.
+ * No counterpart in the reference; the Lmax a caller sees (cg_info.lmax) does not depend on it. */
+int cg_set_plane_budget(cg_grid* g, int max_planes);
+
 /* clearAll() (cg1:223-227): empty every column, keep Lmax. */
 int cg_clear(cg_grid* g);
 

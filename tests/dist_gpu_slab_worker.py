@@ -2,7 +2,8 @@
 sharing GPU 0.  RCCL refuses two ranks on one device ("Duplicate GPU detected"), so on a one-GPU
 box the exchange goes over gloo with device tensors (PROBE_BACKEND=gloo); with one GPU per rank
 the same worker runs over nccl.  Launch: python -m torch.distributed.run --nproc-per-node 2 <this file>"""
-import os, sys
+import faulthandler, os, sys
+faulthandler.dump_traceback_later(45, exit=True)      # a hung rank says where it hangs
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np

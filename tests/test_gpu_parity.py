@@ -389,13 +389,16 @@ def test_material_2_laid_down_as_a_film():
     g.close()
 
 
-def test_many_deposit_steps_recycle_planes():
-    """Every depositing launch takes a plane of its own; with 32 planes and 90 deposits on short
-    columns the engine has to compact the columns several times.  Oracle equality after every step,
-    snapshots across a compaction included."""
+@pytest.mark.parametrize("budget", [32, None])
+def test_many_deposit_steps_recycle_planes(budget):
+    """Every depositing launch takes a plane of its own.  With a budget of 32 planes and 90 deposits on
+    short columns the engine has to compact the columns several times; without one it maps more planes
+    behind the old ones.  Oracle equality after every step, snapshots across a compaction / growth included."""
     fem = _engine()
     nx, ny = 72, 64
     g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    if budget:
+        g.set_plane_budget(budget)
     o = OracleGrid(2 * nx, 2 * ny, 2, 2)
     rng = _lcg(9)
     masks = []
