@@ -286,6 +286,14 @@ static napi_value js_release_scratch(napi_env env, napi_callback_info info) {   
     return undefined(env);
 }
 
+static napi_value js_set_plane_budget(napi_env env, napi_callback_info info) {   /* cg_set_plane_budget */
+    ARGS(env, info, 2);
+    cg_grid* g = grid_of(env, argv[0]); if (!g) return NULL;
+    int32_t n; if (!get_int(env, argv[1], &n)) return NULL;
+    int rc = cg_set_plane_budget(g, n); if (rc) return throw_cg(env, g, rc);
+    return undefined(env);
+}
+
 /* ---- single-column accessors ------------------------------------------------------------------ */
 static napi_value js_add_layer(napi_env env, napi_callback_info info) {          /* cg_add_layer */
     ARGS(env, info, 6);
@@ -404,7 +412,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"etchWetStep", js_etch_wet_step}, {"etchWet", js_etch_wet}, {"depositAld", js_deposit_ald},
         {"aldCollectSeeds", js_ald_collect_seeds}, {"aldDropSeeds", js_ald_drop_seeds}, {"aldIncrement", js_ald_increment},
         {"aldCoat", js_ald_coat}, {"releaseScratch", js_release_scratch},
-        {"addLayer", js_add_layer}, {"removeTopLayer", js_remove_top_layer},
+        {"addLayer", js_add_layer}, {"removeTopLayer", js_remove_top_layer}, {"setPlaneBudget", js_set_plane_budget},
     };
     for (size_t k = 0; k < sizeof fns / sizeof fns[0]; k++) {
         napi_value f;

@@ -233,6 +233,7 @@ class ColumnGrid {
     addon.addLayer(this._h, i | 0, j | 0, matId & 255, Number(z0_real), Number(z1_real)); this._touched();
   }
   removeTopLayer(i, j) { addon.removeTopLayer(this._h, i | 0, j | 0); this._touched(); }                  // cg1:213
+  setPlaneBudget(maxPlanes) { addon.setPlaneBudget(this._h, maxPlanes | 0); }   // engine knob, no counterpart in the reference
   _nextPowerOf2(n) { return 1 << (32 - Math.clz32(Math.max(1, n - 1))); }                                 // cg1:302
   _clamp(v, lo, hi) { return Math.max(lo, Math.min(hi, v)); }                                             // cg1:309
   getLen(i, j) { return this.cols.len[this._colIndex(i, j)]; }
