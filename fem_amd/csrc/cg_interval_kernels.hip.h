@@ -23,6 +23,12 @@
 
 namespace cgk {
 
+// Monotone device-wide maxima / minima: one same-address atomic per wave serialises (a million
+// of them cost 10 ms at 8192^2), so a wave first looks at the current value and only joins in when
+// it would change it.
+__device__ __forceinline__ void lazy_max(int* p, int v) { if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v); }
+__device__ __forceinline__ void lazy_min(int* p, int v) { if (v < __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(p, v); }
+
 // ------------------------------------------------------------------------------------------
 // writing a column as a stream of (z0, z1, material) pieces in ascending order
 // ------------------------------------------------------------------------------------------
@@ -51,7 +57,7 @@ struct ColWriter {
         if (gap) flags[2] = 1;
         if (cav) flags[1] = 1;
         if (bad || w > 255) flags[0] = 1;
-        if (w > flags[3]) atomicMax(&flags[3], w);
+        lazy_max(&flags[3], w);
     }
 };
 
@@ -311,7 +317,7 @@ __global__ void k_ald_air(GridView g, AldLayout L, uint16_t* __restrict__ air_n,
     }
     if (!FILL) {
         for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_down(nmax, o, 64));
-        if ((threadIdx.x & 63) == 0 && nmax > 0) atomicMax(&flags[3], nmax);
+        if ((threadIdx.x & 63) == 0 && nmax > 0) lazy_max(&flags[3], nmax);
     }
 }
 
@@ -371,8 +377,8 @@ __global__ __launch_bounds__(256) void k_ald_seeds(GridView g, unsigned H0q, con
         nmax = max(nmax, __shfl_down(nmax, o, 64)); nsum += __shfl_down(nsum, o, 64);
     }
     if ((threadIdx.x & 63) == 0) {
-        if (!FILL) { if (nmax > 0) atomicMax(&flags[3], nmax); if (nsum) atomicAdd(total, nsum); }
-        else if (imax >= 0) { atomicMin(&bbox[0], imin); atomicMax(&bbox[1], imax); atomicMin(&bbox[2], jmin); atomicMax(&bbox[3], jmax); }
+        if (!FILL) { if (nmax > 0) lazy_max(&flags[3], nmax); if (nsum) atomicAdd(total, nsum); }
+        else if (imax >= 0) { lazy_min(&bbox[0], imin); lazy_max(&bbox[1], imax); lazy_min(&bbox[2], jmin); lazy_max(&bbox[3], jmax); }
     }
 }
 
