@@ -422,6 +422,16 @@ def test_many_deposit_steps_recycle_planes(budget):
             assert g.checksum() == o.checksum()
     assert g.Lmax == o.Lmax == 32
     _assert_same(g, o.arrays(), "final")
+    # the incremental models size their scratch planes by the planes in use: the grid gives back what
+    # the 90 deposits mapped beyond that, then works out of place, then takes deposits again
+    g.etch_wet(255, 3.0); o.etch_wet(255, 3.0)
+    assert g.checksum() == o.checksum(), "etch_wet after the long run"
+    g.deposit_ALD(6, 2.5); o.deposit_ALD(6, 2.5)
+    assert g.checksum() == o.checksum(), "deposit_ALD after the long run"
+    for k in range(40):
+        g.deposit_general(masks[k % 3][0], 3 + k % 3, 1.0, 0); o.deposit_general(masks[k % 3][1], 3 + k % 3, 1.0, 0)
+    assert g.Lmax == o.Lmax
+    _assert_same(g, o.arrays(), "after trimming and growing again")
     g.close()
 
 
