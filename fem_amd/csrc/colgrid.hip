@@ -551,7 +551,8 @@ int take_append_plane(cg_grid* g, int* P) {
     return CG_OK;
 }
 
-// vertical deposit with the plane-overflow protocol (see k_depo_vertical)
+// vertical deposit: the 4-column kernel while every column has a plane to spare, otherwise the
+// one-column kernel with the growth protocol of the reference (an append that finds no room)
 int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
     int P = 0;
     { int rcp = take_append_plane(g, &P); if (rcp) return rcp; }
