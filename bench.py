@@ -139,12 +139,18 @@ def main():
         masks = build_masks(fem_amd, flows, grid, specs, names, nxl, ny, rank * nxl, LX, LY, device)
         slab = SlabGrid(grid, rank, world, device=device, dx=2.0, dy=2.0, ny=ny)
 
+        # C5 also extracts cross-sections after every step: 64 YZ lines at i = 512 s + 256 and 64 XZ lines
+        # at the same j, into device buffers in the reference layout (one launch per axis)
+        slice_idx = [(512 * q + 256) % min(nxl, ny) for q in range(64)] if (args.flow == "c5" and world == 1) else None
+
         def run(nsteps, start=0):
             k = start
             for _ in range(nsteps):
                 if k % len(flow) == 0:
                     slab.createNewGrid()
                 flows.apply_step(slab, flow[k % len(flow)], masks)
+                if slice_idx:
+                    grid.slices_device("YZ", slice_idx); grid.slices_device("XZ", slice_idx)
                 k += 1
             return k
 
@@ -225,7 +231,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16 heights, f64/f32 arithmetic",
             "data": "synthetic",
-            "config": {"workload": f"{args.flow.upper()} flow ({len(flow)} process steps, 3 masks) on a {nxl}x{ny} column grid per GPU",
+            "config": {"workload": f"{args.flow.upper()} flow ({len(flow)} process steps, 3 masks{', 128 cross-sections after every step' if slice_idx else ''}) on a {nxl}x{ny} column grid per GPU",
                        "grid": [nxg, ny], "lmax": grid.Lmax, "parallelism": f"slab{world}"},
             "whole_flow_algorithmic_GBps": round(total_alg * world / 1e9 / dt, 1),
             "checksum": "%016x" % check,

@@ -1298,29 +1298,78 @@ __global__ void k_edit_column(GridView g, size_t c, int op, int mat, unsigned z0
 // ------------------------------------------------------------------------------------------
 // layout conversion: device intervals <-> the reference's column-major host layout
 // ------------------------------------------------------------------------------------------
+// One column (l device intervals in col[]) as a row of the reference layout: L slots of mat and of
+// (z0, z1), gaps skipped, slots past the last layer zero.  Returns the number of layers.  When L
+// is a multiple of 4 the row goes out as 4-byte / 16-byte stores (rows of neighbouring threads are
+// adjacent, so a wave fills whole lines); scalar stores otherwise.
+__device__ __forceinline__ int store_reference_row(const uint32_t* col, int l, int L, uint8_t* __restrict__ mrow, uint16_t* __restrict__ zrow) {
+    int w = 0; unsigned prev = 0;
+    if ((L & 3) == 0) {
+        int k = 0;
+        for (int base = 0; base < L; base += 4) {
+            uint32_t m4 = 0; u16x4 za = (u16x4)(0), zb = (u16x4)(0);      // slots base..base+1 and base+2..base+3
+            for (int q = 0; q < 4; q++) {
+                uint32_t r = 0; bool have = false;
+                while (k < l) {
+                    r = col[k++];
+                    if (!rec_hole(r)) { have = true; break; }
+                    prev = rec_z1(r);
+                }
+                if (!have) break;
+                m4 |= (uint32_t)rec_mat(r) << (8 * q);
+                if (q < 2) { za[2 * q] = (unsigned short)prev; za[2 * q + 1] = (unsigned short)rec_z1(r); }
+                else { zb[2 * (q - 2)] = (unsigned short)prev; zb[2 * (q - 2) + 1] = (unsigned short)rec_z1(r); }
+                prev = rec_z1(r); w++;
+            }
+            *(uint32_t*)(mrow + base) = m4;
+            *(u16x4*)(zrow + 2 * base) = za;
+            *(u16x4*)(zrow + 2 * base + 4) = zb;
+        }
+        return w;
+    }
+    for (int k = 0; k < l; k++) {
+        const uint32_t r = col[k];
+        if (!rec_hole(r) && w < L) { mrow[w] = (uint8_t)rec_mat(r); zrow[2 * w] = (uint16_t)prev; zrow[2 * w + 1] = (uint16_t)rec_z1(r); w++; }
+        prev = rec_z1(r);
+    }
+    for (int k = w; k < L; k++) { mrow[k] = 0; zrow[2 * k] = 0; zrow[2 * k + 1] = 0; }
+    return w;
+}
+
 // Gather `ncols` columns (column s of the output is device column col0 + s*col_stride) into
 // reference layout with stride L: omat[s*L+k], ozp[2*(s*L+k)+{0,1}], olen[s]; gaps are skipped,
 // slots at and above the layer count are zero.
-__global__ __launch_bounds__(256) void k_gather_columns(GridView g, size_t col0, size_t col_stride, size_t ncols, int L,
+// count_chain: the grid is in split form and len[] is behind (see k_relen): count the chain instead.
+__global__ __launch_bounds__(256) void k_gather_columns(GridView g, size_t col0, size_t col_stride, size_t ncols, int L, int count_chain,
                                                         uint8_t* __restrict__ omat, uint16_t* __restrict__ ozp, uint8_t* __restrict__ olen) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < ncols; s += stride) {
         const size_t c = col0 + s * col_stride;
-        const int l = g.len[c];
+        int l = 0;
+        if (!count_chain) l = g.len[c];
+        else if (g.top[c] != 0) { l = 1; for (int p = g.link[c]; p != LINK_NONE && l < 255; p = g.prv[(size_t)p * g.N + c]) l++; }
         uint32_t col[256];
         load_column(g, c, l, col);
-        int w = 0; unsigned prev = 0;
-        for (int k = 0; k < l; k++) {
-            const uint32_t r = col[k];
-            if (!rec_hole(r) && w < L) {
-                const size_t o = s * (size_t)L + w;
-                omat[o] = (uint8_t)rec_mat(r); ozp[2 * o] = (uint16_t)prev; ozp[2 * o + 1] = (uint16_t)rec_z1(r);
-                w++;
-            }
-            prev = rec_z1(r);
-        }
-        olen[s] = (uint8_t)w;
-        for (int k = w; k < L; k++) { const size_t o = s * (size_t)L + k; omat[o] = 0; ozp[2 * o] = 0; ozp[2 * o + 1] = 0; }
+        olen[s] = (uint8_t)store_reference_row(col, l, L, omat + s * (size_t)L, ozp + 2 * s * (size_t)L);
+    }
+}
+
+// `count` cross-sections in one launch: slice s is row index[s] (axis 0: columns index[s]*ny + p) or
+// column index[s] (axis 1: columns p*ny + index[s]), p < line; output as in k_gather_columns, slice
+// after slice.
+__global__ __launch_bounds__(256) void k_gather_slices(GridView g, int axis, const int32_t* __restrict__ index, int count, size_t line, int L,
+                                                       int count_chain, uint8_t* __restrict__ omat, uint16_t* __restrict__ ozp, uint8_t* __restrict__ olen) {
+    const size_t total = (size_t)count * line;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
+        const size_t q = s / line, p = s - q * line;
+        const size_t c = axis == 0 ? (size_t)index[q] * g.ny + p : p * g.ny + (size_t)index[q];
+        int l = 0;
+        if (!count_chain) l = g.len[c];
+        else if (g.top[c] != 0) { l = 1; for (int pl = g.link[c]; pl != LINK_NONE && l < 255; pl = g.prv[(size_t)pl * g.N + c]) l++; }
+        uint32_t col[256];
+        load_column(g, c, l, col);
+        olen[s] = (uint8_t)store_reference_row(col, l, L, omat + s * (size_t)L, ozp + 2 * s * (size_t)L);
     }
 }
 

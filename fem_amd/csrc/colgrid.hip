@@ -111,6 +111,7 @@ struct cg_grid {
     unsigned long long* d_stats = nullptr; bool stats_on = false; uint64_t stats_host[CG_NSTAT] = {0};
     // slice staging
     uint8_t* sl_mat = nullptr; uint16_t* sl_zp = nullptr; uint8_t* sl_len = nullptr; size_t sl_cap = 0;
+    int32_t* sl_idx = nullptr; int sl_idx_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per-kernel timing (cg_profile): event pairs recorded around launches, resolved on read
     bool prof_on = false;
@@ -920,6 +921,7 @@ int cg_destroy(cg_grid* g) {
     if (g->sl_mat) (void)hipFree(g->sl_mat);
     if (g->sl_zp) (void)hipFree(g->sl_zp);
     if (g->sl_len) (void)hipFree(g->sl_len);
+    if (g->sl_idx) (void)hipFree(g->sl_idx);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->own_stream) (void)hipStreamDestroy(g->own_stream);
@@ -1637,7 +1639,7 @@ int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
     HIPCHK(g, hipMalloc(&dm, chunk * L)); HIPCHK(g, hipMalloc(&dz, chunk * L * 4)); HIPCHK(g, hipMalloc(&dl, chunk));
     for (size_t c0 = 0; c0 < g->N; c0 += chunk) {
         size_t n = std::min(chunk, g->N - c0);
-        hipLaunchKernelGGL(k_gather_columns, dim3(blocks_for(n)), dim3(256), 0, g->stream, view(g), c0, (size_t)1, n, L, dm, dz, dl);
+        hipLaunchKernelGGL(k_gather_columns, dim3(blocks_for(n)), dim3(256), 0, g->stream, view(g), c0, (size_t)1, n, L, 0, dm, dz, dl);
         HIPCHK(g, hipGetLastError());
         HIPCHK(g, hipMemcpyAsync(mat + c0 * L, dm, n * L, hipMemcpyDeviceToHost, g->stream));
         HIPCHK(g, hipMemcpyAsync(zpair + 2 * c0 * L, dz, n * L * 4, hipMemcpyDeviceToHost, g->stream));
@@ -1744,7 +1746,6 @@ int cg_snapshot_drop(cg_grid* g, int slot) {
 int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count, void** d_mat, void** d_zpair, void** d_len) {
     NEED(g);
     if ((axis != 0 && axis != 1) || !index || count < 1) return fail(g, CG_ERR_ARG, "bad slice request");
-    { int rc = ensure_len(g); if (rc) return rc; }
     const size_t line = axis == 0 ? (size_t)g->ny : (size_t)g->nx;
     const int L = g->lmax_vis;
     const size_t need = line * count;
@@ -1760,12 +1761,15 @@ int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count, void
         HIPCHK(g, hipMalloc(&g->sl_mat, need * L)); HIPCHK(g, hipMalloc(&g->sl_zp, need * L * 4)); HIPCHK(g, hipMalloc(&g->sl_len, need));
         g->sl_cap = need * L;
     }
-    for (int s = 0; s < count; s++) {
-        size_t col0 = axis == 0 ? (size_t)index[s] * g->ny : (size_t)index[s];
-        size_t stride = axis == 0 ? 1 : (size_t)g->ny;
-        hipLaunchKernelGGL(k_gather_columns, dim3(blocks_for(line)), dim3(256), 0, g->stream, view(g), col0, stride, line, L,
-                           g->sl_mat + s * line * L, g->sl_zp + 2 * s * line * L, g->sl_len + s * line);
+    if (count > g->sl_idx_cap) {
+        if (g->sl_idx) (void)hipFree(g->sl_idx);
+        g->sl_idx = nullptr; g->sl_idx_cap = 0;
+        HIPCHK(g, hipMalloc(&g->sl_idx, (size_t)count * sizeof(int32_t)));
+        g->sl_idx_cap = count;
     }
+    HIPCHK(g, hipMemcpyAsync(g->sl_idx, index, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+    hipLaunchKernelGGL(k_gather_slices, dim3(blocks_for(need)), dim3(256), 0, g->stream, view(g), axis, g->sl_idx, count, line, L,
+                       (g->split && !g->len_valid) ? 1 : 0, g->sl_mat, g->sl_zp, g->sl_len);
     HIPCHK(g, hipGetLastError());
     if (d_mat) *d_mat = g->sl_mat;
     if (d_zpair) *d_zpair = g->sl_zp;
