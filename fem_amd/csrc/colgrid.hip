@@ -111,7 +111,7 @@ struct cg_grid {
     unsigned long long* d_stats = nullptr; bool stats_on = false; uint64_t stats_host[CG_NSTAT] = {0};
     // slice staging
     uint8_t* sl_mat = nullptr; uint16_t* sl_zp = nullptr; uint8_t* sl_len = nullptr; size_t sl_cap = 0;
-    int32_t* sl_idx = nullptr; int sl_idx_cap = 0;
+    int32_t* sl_idx = nullptr; int sl_idx_cap = 0; std::vector<int32_t> sl_idx_host; int sl_idx_axis = -1;   // the request last uploaded
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per-kernel timing (cg_profile): event pairs recorded around launches, resolved on read
     bool prof_on = false;
@@ -1765,9 +1765,15 @@ int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count, void
         if (g->sl_idx) (void)hipFree(g->sl_idx);
         g->sl_idx = nullptr; g->sl_idx_cap = 0;
         HIPCHK(g, hipMalloc(&g->sl_idx, (size_t)count * sizeof(int32_t)));
-        g->sl_idx_cap = count;
+        g->sl_idx_cap = count; g->sl_idx_host.clear();
     }
-    HIPCHK(g, hipMemcpyAsync(g->sl_idx, index, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+    // the same lines are usually asked for step after step: their indices are uploaded once (the
+    // copy from pageable memory would stall the caller until the stream has drained)
+    if (g->sl_idx_host.size() != (size_t)count || memcmp(g->sl_idx_host.data(), index, (size_t)count * sizeof(int32_t)) != 0) {
+        HIPCHK(g, hipMemcpyAsync(g->sl_idx, index, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        g->sl_idx_host.assign(index, index + count);
+    }
     hipLaunchKernelGGL(k_gather_slices, dim3(blocks_for(need)), dim3(256), 0, g->stream, view(g), axis, g->sl_idx, count, line, L,
                        (g->split && !g->len_valid) ? 1 : 0, g->sl_mat, g->sl_zp, g->sl_len);
     HIPCHK(g, hipGetLastError());
