@@ -60,6 +60,7 @@ struct ConfKernel {
 struct Elastic {
     char* base = nullptr; size_t reserved = 0, mapped = 0, unit = 0;      // unit: bytes of every chunk
     std::vector<hipMemGenericAllocationHandle_t> chunks;
+    bool plain = false;     // device without virtual memory management: one hipMalloc block, growth copies (base changes)
 };
 
 struct Snapshot {
@@ -201,7 +202,10 @@ unsigned blocks_for(size_t n) {
 
 // ---- elastic buffers ---------------------------------------------------------------------------
 int el_reserve(cg_grid* g, Elastic& e, size_t bytes, size_t unit_bytes) {
-    if (e.base) return CG_OK;
+    if (e.base || e.plain) return CG_OK;
+    int vmm = 0;
+    if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, g->device) != hipSuccess) { (void)hipGetLastError(); vmm = 0; }
+    if (!vmm || getenv("CG_NO_VMM")) { e.plain = true; e.reserved = bytes; e.unit = std::max<size_t>(unit_bytes, 1); e.mapped = 0; return CG_OK; }
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = g->device;
     size_t gran = 0;
@@ -218,6 +222,19 @@ int el_reserve(cg_grid* g, Elastic& e, size_t bytes, size_t unit_bytes) {
 }
 // Make at least `bytes` of the buffer usable (growth), or give back the chunks beyond them (shrink).
 int el_resize(cg_grid* g, Elastic& e, size_t bytes) {
+    if (e.plain) {
+        if (bytes <= e.mapped && e.base) return CG_OK;                 // never shrinks
+        const size_t want = std::max<size_t>(bytes, 16);
+        char* nb = nullptr;
+        if (hipMalloc(&nb, want) != hipSuccess) { (void)hipGetLastError(); return fail(g, CG_ERR_NOMEM, "no device memory for %zu bytes of planes", want); }
+        if (e.base) {
+            HIPCHK(g, hipMemcpyAsync(nb, e.base, e.mapped, hipMemcpyDeviceToDevice, g->stream));
+            HIPCHK(g, hipStreamSynchronize(g->stream));
+            (void)hipFree(e.base);
+        }
+        e.base = nb; e.mapped = want;
+        return CG_OK;
+    }
     const size_t want = (bytes + e.unit - 1) / e.unit * e.unit;
     if (want > e.reserved) return fail(g, CG_ERR_NOMEM, "elastic buffer: %zu bytes asked, %zu reserved", want, e.reserved);
     while (e.mapped < want) {
@@ -248,6 +265,7 @@ int el_resize(cg_grid* g, Elastic& e, size_t bytes) {
     return CG_OK;
 }
 void el_free(Elastic& e) {
+    if (e.plain) { if (e.base) (void)hipFree(e.base); e.base = nullptr; e.mapped = 0; e.plain = false; return; }
     while (!e.chunks.empty()) {
         const hipMemGenericAllocationHandle_t h = e.chunks.back(); e.chunks.pop_back();
         e.mapped -= e.unit;
@@ -342,6 +360,7 @@ int grow_planes(cg_grid* g, int add = 16) {
     if (newL == g->lmax) return CG_OK;
     int rc = el_resize(g, g->rec_el, 4 * g->N * (size_t)newL); if (rc) return rc;
     rc = el_resize(g, g->prv_el, g->N * (size_t)newL); if (rc) return rc;
+    g->rec = (uint32_t*)g->rec_el.base; g->prv = (uint8_t*)g->prv_el.base;       // (unchanged unless the device lacks VMM)
     g->lmax = newL;
     return CG_OK;
 }
