@@ -69,6 +69,7 @@ def _lib():
     L.og_index_from_pos.argtypes = [vp, i, d]
     L.og_etch_wet.argtypes = [vp, i, d, d, i]
     L.og_etch_wet_step.argtypes = [vp, i, i, i]
+    L.og_etch_wet_step_part.argtypes = [vp, i, i, i, i]
     L.og_deposit_ald.argtypes = [vp, i, d, d, i]
     L.og_slider_reset.argtypes = [vp]
     L.og_slider_ald_entries.argtypes = [vp]
@@ -168,6 +169,11 @@ class OracleGrid:
 
     def etch_wet_step(self, mat, dtq, diagonal):
         rc = self.L.og_etch_wet_step(self.h, mat, dtq, int(bool(diagonal)))
+        if rc:
+            raise RuntimeError("the reference throws here (etch_wet step rc=%d)" % rc)
+
+    def etch_wet_step_part(self, mat, dtq, diagonal, hq):
+        rc = self.L.og_etch_wet_step_part(self.h, mat, dtq, int(bool(diagonal)), int(hq))
         if rc:
             raise RuntimeError("the reference throws here (etch_wet step rc=%d)" % rc)
 

@@ -128,6 +128,41 @@ class OracleSlabEngine:
                 top_q = max(top_q, int(zp[c, ln[c] - 1, 1]))
         return gaps, cav, int(ln.max()) * 2 + 1 if ln.size else 0, top_q      # gaps are intervals of their own on the wire
 
+    def etch_wet_step_slab(self, matId, dt_q, diagonal, hmax_q, planes, ghost_lower, ghost_upper):
+        """One etch_wet increment of this slab: the ghost rows are put below / above the slab's own rows
+        in a scratch grid, the reference's increment runs on that (a cut reaches one column sideways),
+        and the slab keeps its own rows of the result."""
+        ln, mat, zp, L = self._layers()
+        lo, up = self._ghost_columns(planes, ghost_lower), self._ghost_columns(planes, ghost_upper)
+        rows = (1 if lo is not None else 0) + self.nx + (1 if up is not None else 0)
+        Lx = max(L, max([len(c) for g_ in (lo, up) if g_ is not None for c in g_] + [1]))
+        eln = np.zeros(rows * self.ny, np.uint8); emat = np.zeros((rows * self.ny, Lx), np.uint8)
+        ezp = np.zeros((rows * self.ny, Lx, 2), np.uint16)
+        r0 = 0
+        def put_ghost(cols, row):
+            for j, lay in enumerate(cols):
+                c = row * self.ny + j; eln[c] = len(lay)
+                for k, (z0, z1, m, _) in enumerate(lay):
+                    emat[c, k] = m; ezp[c, k] = (z0, z1)
+        if lo is not None:
+            put_ghost(lo, 0); r0 = 1
+        a, b = r0 * self.ny, (r0 + self.nx) * self.ny
+        eln[a:b] = ln; emat[a:b, :L] = mat; ezp[a:b, :L] = zp
+        if up is not None:
+            put_ghost(up, r0 + self.nx)
+        scratch = OracleGrid(dx=self.dx, dy=self.dy, slab=(rows, self.ny, 0, rows), lmax=Lx)
+        scratch.upload(eln, emat.reshape(-1), ezp.reshape(-1), Lx)
+        scratch.etch_wet_step_part(matId, dt_q, diagonal, max(int(hmax_q), 1))
+        sl, sm, sz = scratch.arrays(); Ls = scratch.Lmax
+        sm = sm.reshape(-1, Ls)[a:b]; sz = sz.reshape(-1, Ls, 2)[a:b]
+        self.o.upload(sl[a:b], sm.reshape(-1), sz.reshape(-1), Ls)
+
+    def release_scratch(self):
+        pass
+
+    _js_round = staticmethod(lambda x: math.floor(x + 0.5))
+    zScale = 0.1
+
     def cavity_fill(self, hmax_q):
         self.o.L.og_cavity_fill.argtypes = [ctypes.c_void_p, ctypes.c_double]
         self.o.L.og_cavity_fill(self.o.h, float(hmax_q) * 0.1)
