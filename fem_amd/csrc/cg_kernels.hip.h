@@ -418,8 +418,10 @@ __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsign
 
 // Vertical deposit / etch (fast paths, cg1:445-454 and 609-618).  A thread owns U groups that
 // are 256 groups apart; all their loads are issued before anything is computed or stored.
+// fresh (deposit without a mask only): every column is empty and top / link have not been cleared
+// since the grid was reset -- nothing is loaded, and the launch leaves both streams defined.
 template <bool ETCH, bool STATS, int U>
-__global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
+__global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* __restrict__ mask, int matId, double t, int fresh,
                                                      int* __restrict__ flags, unsigned long long* gstats) {
     unsigned loc[3] = {0, 0, 0};
     const bool isAll = (matId == 255);
@@ -446,7 +448,8 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
             if (gi < ngroups) {
                 const size_t c0 = gi << 2;
                 open[u] = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
-                if (open[u]) {
+                if (!ETCH && fresh) lk[u] = splat4(LINK_NONE);
+                else if (open[u]) {
                     lk[u] = ld_u8x4(g.link + c0);
                     tv[u] = ld_rec4(g.top + c0);
                 }
@@ -459,7 +462,10 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
             if (STATS) loc[0] += __popc(open[u]);
             if (ETCH) { const uint32_t nb[4] = {0, 0, 0, 0}; const int np[4] = {0, 0, 0, 0};
                         etch_group4<STATS>(g, c0, open[u], dz, matId, isAll, tv[u], lk[u], 0u, nb, np, loc[1], loc[2]); }
-            else depo_group4<STATS>(g, c0, open[u], dz, matId, tv[u], lk[u], loc[1], loc[2]);
+            else {
+                depo_group4<STATS>(g, c0, open[u], dz, matId, tv[u], lk[u], loc[1], loc[2]);
+                if (fresh) st_u8x4(g.link + c0, splat4(LINK_NONE));
+            }
         }
     }
     if (STATS) {

@@ -96,6 +96,7 @@ struct cg_grid {
     int nextp = 0;                                        // split form: first plane no interval lives in yet
     bool split = true;                                    // which form the columns are in right now
     bool len_valid = true;                                // split form: len[] agrees with the chains (see ensure_len)
+    bool pristine = false;                                // every column is empty, but len / top / link still hold old bytes (see zero_planes)
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<uint8_t*> masks;
     std::deque<ConfKernel*> kcache;
@@ -168,10 +169,15 @@ struct ProfScope {
                         hipGetErrorString(e__), __FILE__, __LINE__);                          \
     } while (0)
 
-#define NEED(g)                                                                               \
+int materialize(cg_grid* g);
+#define NEED_H(g)                                                                             \
     do { if (!(g)) return fail(nullptr, CG_ERR_ARG, "null handle");                           \
          hipError_t e__ = hipSetDevice((g)->device);                                          \
          if (e__ != hipSuccess) return fail(g, CG_ERR_HIP, "hipSetDevice(%d): %s", (g)->device, hipGetErrorString(e__)); } while (0)
+// entry points that read or write the columns: a grid that was reset but whose streams have not
+// been cleared yet (see zero_planes) is cleared first
+#define NEED(g)                                                                               \
+    do { NEED_H(g); { int rcm__ = materialize(g); if (rcm__) return rcm__; } } while (0)
 
 double js_round(double x) { double r = std::floor(x); if (x - r >= 0.5) r += 1.0; return r; }
 
@@ -305,16 +311,24 @@ int alloc_planes(cg_grid* g, int lmax) {
     return CG_OK;
 }
 
-// Empty every column.  Only len / top / link are reset: plane slots at or above a column's
-// length hold unspecified data and nothing reads them.
+// Empty every column.  Nothing is cleared here: the grid is marked pristine, and either the next
+// step is a deposit without a mask -- then the kernel treats every column as empty and writes top and
+// link of all of them itself -- or whatever touches the columns first clears len / top / link
+// (materialize).  Plane slots hold unspecified data anyway and nothing reads them.
 int zero_planes(cg_grid* g, bool all = true) {
     (void)all;
+    g->pristine = true;
+    g->split = true; g->nextp = 0; g->len_valid = false;
+    g->len_bound = 0; g->has_gaps = false; g->has_cavity = false;
+    return CG_OK;
+}
+int materialize(cg_grid* g) {
+    if (!g->pristine) return CG_OK;
     ProfScope ps(g, CG_K_CLEAR);
     HIPCHK(g, hipMemsetAsync(g->len, 0, g->N, g->stream));
     HIPCHK(g, hipMemsetAsync(g->top, 0, 4 * g->N, g->stream));
     HIPCHK(g, hipMemsetAsync(g->link, 0xff, g->N, g->stream));        // LINK_NONE: nothing below
-    g->split = true; g->nextp = 0; g->len_valid = true;
-    g->len_bound = 0; g->has_gaps = false; g->has_cavity = false;
+    g->pristine = false; g->len_valid = true;
     return CG_OK;
 }
 
@@ -859,10 +873,12 @@ static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, 
     size_t nb = (g->N / 4 + (size_t)256 * U - 1) / ((size_t)256 * U);
     if (cap > 0) nb = std::min<size_t>(nb, (size_t)cap);
     const dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>(nb, 0x7fffffff))), blk(256);
-#define LV(S, UU) hipLaunchKernelGGL((k_vertical_g4<ETCH, S, UU>), grid, blk, 0, g->stream, gv, mask, mat, t, g->d_flags, g->d_stats)
+    const int fresh = (!ETCH && g->pristine) ? 1 : 0;
+#define LV(S, UU) hipLaunchKernelGGL((k_vertical_g4<ETCH, S, UU>), grid, blk, 0, g->stream, gv, mask, mat, t, fresh, g->d_flags, g->d_stats)
     if (g->stats_on) { if (U == 1) LV(true, 1); else if (U == 2) LV(true, 2); else LV(true, 4); }
     else { if (U == 1) LV(false, 1); else if (U == 2) LV(false, 2); else LV(false, 4); }
 #undef LV
+    if (fresh) g->pristine = false;          // top and link are defined now; len is behind as after any such launch
 }
 
 // =============================================================================================
@@ -949,7 +965,7 @@ int cg_destroy(cg_grid* g) {
 }
 
 int cg_reset(cg_grid* g, int lmax_init) {
-    NEED(g);
+    NEED_H(g);
     int lmax = next_pow2(lmax_init > 0 ? lmax_init : g->lmax_vis);
     if (lmax > 256) lmax = 256;
     g->pend.active = false;
@@ -960,13 +976,13 @@ int cg_reset(cg_grid* g, int lmax_init) {
 }
 
 int cg_set_plane_budget(cg_grid* g, int max_planes) {
-    NEED(g);
+    NEED_H(g);
     if (max_planes < 1) return fail(g, CG_ERR_ARG, "plane budget %d", max_planes);
     g->plane_budget = std::min(max_planes, MAX_PLANES);
     return CG_OK;
 }
 
-int cg_clear(cg_grid* g) { NEED(g); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
+int cg_clear(cg_grid* g) { NEED_H(g); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
 
 int cg_get_info(const cg_grid* g, cg_info* o) {
     if (!g || !o) return CG_ERR_ARG;
@@ -978,13 +994,13 @@ int cg_get_info(const cg_grid* g, cg_info* o) {
 }
 
 int cg_set_stream(cg_grid* g, void* s) {
-    NEED(g);
+    NEED_H(g);
     HIPCHK(g, hipStreamSynchronize(g->stream));
     g->stream = s ? (hipStream_t)s : g->own_stream;
     return CG_OK;
 }
 
-int cg_sync(cg_grid* g) { NEED(g); HIPCHK(g, hipStreamSynchronize(g->stream)); return CG_OK; }
+int cg_sync(cg_grid* g) { NEED_H(g); HIPCHK(g, hipStreamSynchronize(g->stream)); return CG_OK; }
 
 // ---- masks ----------------------------------------------------------------------------------
 static int new_mask_slot(cg_grid* g, uint8_t** buf, int* id) {
@@ -996,7 +1012,7 @@ static int new_mask_slot(cg_grid* g, uint8_t** buf, int* id) {
 }
 
 int cg_mask_from_raster(cg_grid* g, const uint8_t* host, size_t n, int* mask_id) {
-    NEED(g);
+    NEED_H(g);
     if (!host || !mask_id || n != g->N) return fail(g, CG_ERR_ARG, "mask raster: need %zu bytes, got %zu", g->N, n);
     uint8_t* buf; int rc = new_mask_slot(g, &buf, mask_id); if (rc) return rc;
     HIPCHK(g, hipMemcpyAsync(buf, host, n, hipMemcpyHostToDevice, g->stream));
@@ -1006,7 +1022,7 @@ int cg_mask_from_raster(cg_grid* g, const uint8_t* host, size_t n, int* mask_id)
 }
 
 int cg_mask_from_device_raster(cg_grid* g, const void* dev, size_t n, int* mask_id) {
-    NEED(g);
+    NEED_H(g);
     if (!dev || !mask_id || n != g->N) return fail(g, CG_ERR_ARG, "mask raster: need %zu bytes, got %zu", g->N, n);
     uint8_t* buf; int rc = new_mask_slot(g, &buf, mask_id); if (rc) return rc;
     hipLaunchKernelGGL(k_mask_normalise, dim3(blocks_for(n)), dim3(256), 0, g->stream, (const uint8_t*)dev, buf, n);
@@ -1015,7 +1031,7 @@ int cg_mask_from_device_raster(cg_grid* g, const void* dev, size_t n, int* mask_
 }
 
 int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const double* pts, int npts, int* mask_id) {
-    NEED(g);
+    NEED_H(g);
     if (!mask_id || nshapes < 0 || npts < 0 || (nshapes > 0 && !shapes) || (npts > 0 && !pts))
         return fail(g, CG_ERR_ARG, "bad shape list");
     for (int s = 0; s < nshapes; s++)
@@ -1038,7 +1054,7 @@ int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const d
 }
 
 int cg_mask_download(cg_grid* g, int mask_id, uint8_t* out, size_t n) {
-    NEED(g);
+    NEED_H(g);
     bool ok; const uint8_t* m = mask_ptr(g, mask_id, &ok);
     if (!ok || !m || !out || n != g->N) return fail(g, CG_ERR_ARG, "bad mask id %d or size", mask_id);
     HIPCHK(g, hipMemcpyAsync(out, m, n, hipMemcpyDeviceToHost, g->stream));
@@ -1047,7 +1063,7 @@ int cg_mask_download(cg_grid* g, int mask_id, uint8_t* out, size_t n) {
 }
 
 int cg_mask_destroy(cg_grid* g, int mask_id) {
-    NEED(g);
+    NEED_H(g);
     bool ok; const uint8_t* m = mask_ptr(g, mask_id, &ok);
     if (!ok || !m) return fail(g, CG_ERR_ARG, "bad mask id %d", mask_id);
     HIPCHK(g, hipStreamSynchronize(g->stream));
@@ -1058,7 +1074,7 @@ int cg_mask_destroy(cg_grid* g, int mask_id) {
 // ---- steps ----------------------------------------------------------------------------------
 int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thickness, double conformality, int has_lower, int has_upper,
                      int* radius_rows) {
-    NEED(g);
+    NEED_H(g);
     if (radius_rows) *radius_rows = 0;
     if (kind != CG_STENCIL_DEPOSIT && kind != CG_STENCIL_ETCH) return fail(g, CG_ERR_ARG, "bad stencil kind %d", kind);
     if (g->pend.active) return fail(g, CG_ERR_STATE, "a stencil step is already open");
@@ -1070,6 +1086,10 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     if (!(t > 0)) return CG_OK;                                           // cg1:437, 600
     const double S = std::max(0.0, std::min(1.0, conformality));          // cg1:440, 603
     const double latRange = t * S;
+    // a reset grid whose first step is a deposit everywhere needs no clearing pass: the kernel writes
+    // top and link of every column itself
+    const bool fresh = g->pristine && kind == CG_STENCIL_DEPOSIT && latRange < std::min(g->dx, g->dy) && !mask && g->N % 4 == 0 && g->lmax >= 1;
+    if (!fresh) { int rcm = materialize(g); if (rcm) return rcm; }
     { int rcs = ensure_split(g); if (rcs) return rcs; }
     stats_begin(g);
     if (kind == CG_STENCIL_DEPOSIT && mat == CG_MAT_CAVITY) g->has_cavity = true;      // a "cavity" laid down as a film
@@ -1114,7 +1134,7 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
 }
 
 int cg_halo_buffers(cg_grid* g, void** send_lower, void** send_upper, void** recv_lower, void** recv_upper, size_t* bytes_each) {
-    NEED(g);
+    NEED_H(g);
     if (!g->pend.active) return fail(g, CG_ERR_STATE, "no stencil step is open");
     if (send_lower) *send_lower = g->halo[0];
     if (send_upper) *send_upper = g->halo[1];
@@ -1125,7 +1145,7 @@ int cg_halo_buffers(cg_grid* g, void** send_lower, void** send_upper, void** rec
 }
 
 int cg_set_halo_buffers(cg_grid* g, void* send_lower, void* send_upper, void* recv_lower, void* recv_upper, size_t bytes_each) {
-    NEED(g);
+    NEED_H(g);
     if (g->pend.active) return fail(g, CG_ERR_STATE, "a stencil step is open");
     HIPCHK(g, hipStreamSynchronize(g->stream));
     if (!g->halo_external) for (auto& h : g->halo) { if (h) (void)hipFree(h); h = nullptr; }
@@ -1520,7 +1540,7 @@ int cg_ald_seed_info(cg_grid* g, int* held, uint64_t* count) {
 }
 
 int cg_ald_drop_seeds(cg_grid* g) {
-    NEED(g);
+    NEED_H(g);
     HIPCHK(g, hipStreamSynchronize(g->stream));
     drop_seeds(g);
     return CG_OK;
@@ -1591,7 +1611,7 @@ int cg_deposit_ald(cg_grid* g, int mat, double total_thickness, double dt) {
 }
 
 int cg_release_scratch(cg_grid* g) {
-    NEED(g);
+    NEED_H(g);
     HIPCHK(g, hipStreamSynchronize(g->stream));
     free_alt(g, 0); free_alt(g, 1);
     return CG_OK;
@@ -1670,12 +1690,13 @@ int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
 }
 
 int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8_t* len, int lmax) {
-    NEED(g);
+    NEED_H(g);
     if (!mat || !zpair || !len || lmax < 1 || lmax > 256) return fail(g, CG_ERR_ARG, "bad upload arguments (lmax=%d)", lmax);
     g->pend.active = false;
     HIPCHK(g, hipStreamSynchronize(g->stream));
     if (lmax > g->lmax) { int rc = grow_planes(g, lmax - g->lmax); if (rc) return rc; }
     g->lmax_vis = lmax;
+    g->pristine = false;                                    // every column is written below
     g->split = false;                                       // the scatter kernel writes whole stacks
     const int L = lmax;
     const size_t chunk = std::min<size_t>(g->N, (size_t)1 << 20);
@@ -1732,7 +1753,7 @@ int cg_snapshot_save(cg_grid* g, int slot) {
 }
 
 int cg_snapshot_load(cg_grid* g, int slot) {
-    NEED(g);
+    NEED_H(g);
     auto it = g->snaps.find(slot);
     if (it == g->snaps.end()) return fail(g, CG_ERR_ARG, "no snapshot in slot %d", slot);
     const Snapshot& s = it->second;
@@ -1747,12 +1768,12 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     g->nextp = s.nextp;
     g->split = s.split;
     g->len_bound = s.len_bound; g->has_gaps = s.has_gaps; g->has_cavity = s.has_cavity;
-    g->lmax_vis = s.lmax_vis; g->len_valid = s.len_valid;
+    g->lmax_vis = s.lmax_vis; g->len_valid = s.len_valid; g->pristine = false;
     return CG_OK;
 }
 
 int cg_snapshot_drop(cg_grid* g, int slot) {
-    NEED(g);
+    NEED_H(g);
     auto it = g->snaps.find(slot);
     if (it == g->snaps.end()) return CG_OK;
     HIPCHK(g, hipStreamSynchronize(g->stream));
@@ -1843,7 +1864,7 @@ int cg_checksum(cg_grid* g, uint64_t* sum) {
 }
 
 int cg_step_stats(cg_grid* g, int enable, uint64_t stats[CG_NSTAT]) {
-    NEED(g);
+    NEED_H(g);
     if (stats) {
         unsigned long long h[CG_NSTAT];
         HIPCHK(g, hipMemcpyAsync(h, g->d_stats, sizeof h, hipMemcpyDeviceToHost, g->stream));
@@ -1856,7 +1877,7 @@ int cg_step_stats(cg_grid* g, int enable, uint64_t stats[CG_NSTAT]) {
 }
 
 int cg_profile(cg_grid* g, int enable, double ms[CG_NKIND], uint64_t count[CG_NKIND]) {
-    NEED(g);
+    NEED_H(g);
     HIPCHK(g, hipStreamSynchronize(g->stream));
     for (auto& r : g->prof_recs) {
         float v = 0;
@@ -1873,10 +1894,10 @@ int cg_profile(cg_grid* g, int enable, double ms[CG_NKIND], uint64_t count[CG_NK
     return CG_OK;
 }
 
-int cg_timer_start(cg_grid* g) { NEED(g); HIPCHK(g, hipEventRecord(g->ev0, g->stream)); return CG_OK; }
+int cg_timer_start(cg_grid* g) { NEED_H(g); HIPCHK(g, hipEventRecord(g->ev0, g->stream)); return CG_OK; }
 
 int cg_timer_stop(cg_grid* g, float* ms) {
-    NEED(g);
+    NEED_H(g);
     HIPCHK(g, hipEventRecord(g->ev1, g->stream));
     HIPCHK(g, hipEventSynchronize(g->ev1));
     float v = 0; HIPCHK(g, hipEventElapsedTime(&v, g->ev0, g->ev1));
