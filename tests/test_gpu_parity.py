@@ -368,6 +368,57 @@ def test_lmax_follows_the_reference_while_columns_have_gaps():
     g.close()
 
 
+def test_first_operation_after_a_reset():
+    """createNewGrid does not clear the column streams; whatever comes first on the reset grid has to
+    see empty columns: an unmasked deposit (which defines the streams itself), or anything else."""
+    fem = _engine()
+    nx, ny = 40, 36
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    half = np.zeros((nx, ny), np.uint8); half[:, :17] = 1
+    gm, om = g.mask_from_raster(half.reshape(-1)), half.reshape(-1)
+
+    def dirty():
+        for grid, m in ((g, gm), (o, om)):
+            grid.deposit_general(None, 3, 7, 0); grid.deposit_general(m, 4, 3, 0); grid.deposit_general(None, 5, 4, 1.0)
+            grid.etch_general(m, 255, 6, 0)
+
+    firsts = {
+        "unmasked deposit": lambda grid, m: grid.deposit_general(None, 6, 2.5, 0),
+        "masked deposit": lambda grid, m: grid.deposit_general(m, 6, 2.5, 0),
+        "conformal deposit": lambda grid, m: grid.deposit_general(m, 6, 4, 1.0),
+        "etch": lambda grid, m: grid.etch_general(None, 255, 3, 0),
+        "lateral etch": lambda grid, m: grid.etch_general(None, 255, 4, 1.0),
+        "cmp": lambda grid, m: grid.cmp(2.0, 0),
+        "strip": lambda grid, m: grid.strip_connected(4),
+        "cavity pass": lambda grid, m: grid.identify_cavity(),
+        "wet etch": lambda grid, m: grid.etch_wet(255, 2.0),
+        "ALD": lambda grid, m: grid.deposit_ALD(6, 2.0),
+        "nothing": lambda grid, m: None,
+    }
+    for name, first in firsts.items():
+        dirty()
+        g.createNewGrid(); o.reset()
+        first(g, gm); first(o, om)
+        assert g.maxHeight() == o.max_height(), name
+        assert g.checksum() == o.checksum(), name
+        _assert_same(g, o.arrays(), name)
+        g.deposit_general(gm, 7, 1.5, 0); o.deposit_general(om, 7, 1.5, 0)        # and life goes on
+        g.etch_general(None, 7, 1.0, 0); o.etch_general(None, 7, 1.0, 0)
+        assert g.checksum() == o.checksum(), name + " / next steps"
+    # accessors, snapshots and uploads on a reset grid
+    dirty(); g.createNewGrid(); o.reset()
+    g.addLayer(3, 4, 5, 0.0, 2.0); o.addLayer(3, 4, 5, 0.0, 2.0)
+    assert g.checksum() == o.checksum()
+    dirty(); g.createNewGrid(); o.reset()
+    g.snapshot_save(1); g.deposit_general(None, 3, 5, 0); g.snapshot_load(1)
+    assert g.checksum() == o.checksum()
+    dirty(); ln, mat, zp = o.arrays(); lm = o.Lmax
+    g.createNewGrid(); g.upload(ln, mat, zp, lm)
+    assert g.checksum() == o.checksum()
+    g.close()
+
+
 def test_material_2_laid_down_as_a_film():
     """Material id 2 is what identify_cavity strips: a flow that deposits it like any film must take
     the full cavity pass after conformal deposits, not the no-gap shortcut."""
