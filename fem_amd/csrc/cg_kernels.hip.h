@@ -703,8 +703,14 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
 template <int R> struct AddTab { float a[(R + 1) * (R + 1)]; int lim[R + 1]; };
 
 // Tile of the symmetric kernel: TJS columns x (1024 / TJS) rows per block of 256 threads.
+// A block stages one tile and updates it in PASSES passes of 1024 columns each.  The halo rows are
+// staged (de-quantised, flags folded in) once per tile, so a taller tile spends less on staging and
+// halo reads per updated row; measured: 5 % faster at R <= 2, slower from R = 3 on (40 % at R = 7).
+constexpr int sym_passes(int R) { return R <= 2 ? 2 : 1; }
 template <int R, int TJS> struct SymGeom {
-    static constexpr int TIS = 1024 / TJS;           // rows per block
+    static constexpr int PASSES = sym_passes(R);
+    static constexpr int TIP = 1024 / TJS;           // rows per pass
+    static constexpr int TIS = TIP * PASSES;         // rows per block
     static constexpr int GX = TJS / 4;               // groups (threads) per row
     static constexpr int Rp = (R + 3) & ~3;          // halo columns rounded up to whole groups
     static constexpr int PITCH = TJS + 2 * Rp;       // floats per LDS row
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                                                      const AddTab<R> tab, const Tap* __restrict__ taps64, int ntaps64,
                                                      int* __restrict__ flags, unsigned long long* gstats) {
     using G = SymGeom<R, TJS>;
-    constexpr int Rp = G::Rp, PITCH = G::PITCH, ROWS = G::ROWS, W = G::W, GPR = G::GPR, TIS = G::TIS, GX = G::GX;
+    constexpr int Rp = G::Rp, PITCH = G::PITCH, ROWS = G::ROWS, W = G::W, GPR = G::GPR, TIS = G::TIS, TIP = G::TIP, GX = G::GX;
     __shared__ __align__(16) float s_h[ROWS * PITCH];
     const int tiles_j = (g.ny + TJS - 1) / TJS;
     int tile_i, tile_j;
@@ -769,9 +775,13 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
     }
     __syncthreads();
 
-    const int gx = threadIdx.x % GX, ry = threadIdx.x / GX;
-    const int il = i_base + ry, j0 = j_base + 4 * gx;
+    const int gx = threadIdx.x % GX;
+    const int j0 = j_base + 4 * gx;
     unsigned loc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int pass = 0; pass < G::PASSES; pass++) {
+    const int ry = threadIdx.x / GX + pass * TIP;
+    const int il = i_base + ry;
     if (il < g.nx && j0 < g.ny) {
         const size_t c0 = (size_t)il * g.ny + j0;
         const u32x4 tv = ld_rec4(g.top + c0);
@@ -885,6 +895,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
             }
         }
         if (!stored && g.top_w != g.top) st_rec4(g.top_w + c0, tv);       // columns that stay as they are
+    }
     }
     if (STATS) {
         if (ETCH) { const int slot[4] = {ST_OPEN, ST_ETCHED, ST_REMOVED, ST_FLOOR}; stats_commit<4>(gstats, loc, slot); }

@@ -676,7 +676,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
             tab.lim[du_] = -1;                                                                                 \
             for (int dv_ = 0; dv_ <= RR; dv_++) if (tab.a[du_ * (RR + 1) + dv_] != -INFINITY) tab.lim[du_] = dv_; \
         }                                                                                                      \
-        const int tis = 1024 / TT;                                                                             \
+        const int tis = 1024 / TT * sym_passes(RR);                                                            \
         const int nb = stencil_bands(g->nx, tis, R, halo_lo != nullptr, halo_up != nullptr, part, bands);      \
         for (int b_ = 0; b_ < nb; b_++) {                                                                      \
             const dim3 gridS(sup_grid(gv, bands[b_].t0, bands[b_].n, (g->ny + TT - 1) / TT));                  \
