@@ -27,10 +27,11 @@ static int vu_setting() {
 }
 template <bool ETCH>
 static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, int P);
-// columns per tile row of the symmetric stencil kernel (tuning knob: env CG_TJS = 64, 128, 256)
-static int sym_tile_cols() {
-    static int v = [] { const char* e = getenv("CG_TJS"); int x = e ? atoi(e) : 64; return (x == 64 || x == 128 || x == 256) ? x : 64; }();
-    return v;
+// columns per tile row of the symmetric stencil kernel: 128 for the memory-bound radii, 64 above
+// (measured: -5 % at R <= 2, +6 % at R = 7 for 128); env CG_TJS = 64, 128, 256 overrides
+static int sym_tile_cols(int Re) {
+    static int v = [] { const char* e = getenv("CG_TJS"); int x = e ? atoi(e) : 0; return (x == 64 || x == 128 || x == 256) ? x : 0; }();
+    return v ? v : (Re <= 2 ? 128 : 64);
 }
 
 namespace {
@@ -516,7 +517,7 @@ int upload_taps(cg_grid* g, ConfKernel* k, int R) {
         std::vector<int> seen(n * n, 0);
         bool ok = true;
         std::vector<Tap> fine_sym;
-        const int pitch_sym = sym_tile_cols() + 2 * ((Re + 3) & ~3);
+        const int pitch_sym = sym_tile_cols(Re) + 2 * ((Re + 3) & ~3);
         for (size_t q = 0; q < k->add.size() && ok; q++) {
             const int a = std::abs(k->du[q]), b = std::abs(k->dv[q]);
             const double scaled = std::ldexp((double)k->add[q], 40);
@@ -668,7 +669,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
     ProfScope ps(g, etch ? CG_K_STENCIL_ETCH : CG_K_STENCIL_DEPOSIT);
     if (sym) {
         g->len_valid = false;
-        const int tjs = sym_tile_cols();
+        const int tjs = sym_tile_cols(K->Re);
 #define SYM(RR, TT, E, S)                                                                                      \
     do {                                                                                                       \
         AddTab<RR> tab; memcpy(tab.a, K->quad.data(), sizeof tab.a);                                           \
