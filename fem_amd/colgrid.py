@@ -89,6 +89,12 @@ ABI = {
     "cg_ald_drop_seeds": (_i, [_vp]),
     "cg_ald_increment": (_i, [_vp, _i, _d]),
     "cg_ald_coat": (_i, [_vp, _i, _d]),
+    "cg_ald_collect_seeds_slab": (_i, [_vp, _d, C.c_uint32, _i, _vp, _vp, C.POINTER(_i), C.POINTER(C.c_uint64)]),
+    "cg_ald_seed_halo_bytes": (_i, [_vp, _i, C.POINTER(_sz)]),
+    "cg_ald_seed_halo_pack": (_i, [_vp, _i, _vp, _vp]),
+    "cg_ald_seed_halo_unpack": (_i, [_vp, _i, _vp, _vp]),
+    "cg_ald_coat_slab": (_i, [_vp, _i, _d, C.c_uint32]),
+    "cg_ald_merge_slab": (_i, [_vp, C.c_uint32]),
     "cg_release_scratch": (_i, [_vp]),
     "cg_set_plane_budget": (_i, [_vp, _i]),
     "cg_add_layer": (_i, [_vp, _i, _i, _i, _d, _d]),
@@ -498,6 +504,34 @@ class ColumnGrid:
         """One etch_wet increment of a slab (no cavity pass): see cg_etch_wet_step_slab."""
         self._chk(self.lib.cg_etch_wet_step_slab(self.h, int(matId), int(dt_q), int(bool(diagonal)), int(hmax_q), int(planes),
                                                  ghost_lower or None, ghost_upper or None))
+
+    # deposit_ALD of a slab: see cg_ald_collect_seeds_slab and the calls listed with it
+    def ald_collect_seeds_slab(self, T, hmax_q, planes, ghost_lower, ghost_upper):
+        """Seeds of this slab's rows; returns the most seeds held by one of its columns."""
+        sp = C.c_int()
+        self._chk(self.lib.cg_ald_collect_seeds_slab(self.h, float(T), int(hmax_q), int(planes), ghost_lower or None, ghost_upper or None,
+                                                     C.byref(sp), None))
+        return sp.value
+
+    def ald_seed_halo_bytes(self, seed_planes):
+        n = C.c_size_t()
+        self._chk(self.lib.cg_ald_seed_halo_bytes(self.h, int(seed_planes), C.byref(n)))
+        return n.value
+
+    def ald_seed_halo_pack(self, seed_planes, send_lower, send_upper):
+        self._chk(self.lib.cg_ald_seed_halo_pack(self.h, int(seed_planes), send_lower, send_upper))
+
+    def ald_seed_halo_unpack(self, seed_planes, recv_lower, recv_upper):
+        self._chk(self.lib.cg_ald_seed_halo_unpack(self.h, int(seed_planes), recv_lower or None, recv_upper or None))
+
+    def ald_coat_slab(self, matId, t, hmax_q):
+        self._chk(self.lib.cg_ald_coat_slab(self.h, int(matId), float(t), int(hmax_q)))
+
+    def ald_merge_slab(self, hbase_q):
+        self._chk(self.lib.cg_ald_merge_slab(self.h, int(hbase_q)))
+
+    def ald_drop_seeds(self):
+        self._chk(self.lib.cg_ald_drop_seeds(self.h))
 
     def release_scratch(self):
         self._chk(self.lib.cg_release_scratch(self.h))

@@ -295,10 +295,12 @@ __device__ __forceinline__ void mark_occupied(const GridView& g, size_t c, const
 struct AldLayout { int Zmax, wpc; uint32_t lastMask; };        // makeBitLayout (cg2:161-167), evaluated on the host
 
 // --- air intervals of every column (buildAirIntervalsAll, cg2:367-385) ---------------------
-// FILL = false: counts only (air_n); FILL = true: writes air[k*N + c] = (s, e) too.
+// FILL = false: counts only (air_n); FILL = true: writes the intervals (s, e) too.  Column c goes to
+// entry off + c of arrays whose planes are `stride` entries apart: a slab keeps the air of its
+// neighbours' boundary rows (ghost columns, viewed as a one-row grid) in the same arrays.
 template <bool FILL>
 __global__ void k_ald_air(GridView g, AldLayout L, uint16_t* __restrict__ air_n, uint2* __restrict__ air, int planes,
-                          int* __restrict__ flags) {
+                          size_t stride_out, size_t off, int* __restrict__ flags) {
     extern __shared__ uint32_t lds[];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const BitCol b{lds + threadIdx.x, (int)blockDim.x, L.wpc};
@@ -310,10 +312,10 @@ __global__ void k_ald_air(GridView g, AldLayout L, uint16_t* __restrict__ air_n,
         b.set(L.wpc - 1, (~b.get(L.wpc - 1)) & L.lastMask);
         int n = 0;
         emit_intervals(b, L.Zmax, [&](int s, int e) {
-            if (FILL && n < planes) air[(size_t)n * g.N + c] = make_uint2((unsigned)s, (unsigned)e);
+            if (FILL && n < planes) air[(size_t)n * stride_out + off + c] = make_uint2((unsigned)s, (unsigned)e);
             n++;
         });
-        if (!FILL) { air_n[c] = (uint16_t)min(n, 65535); nmax = max(nmax, n); }
+        if (!FILL) { air_n[off + c] = (uint16_t)min(n, 65535); nmax = max(nmax, n); }
     }
     if (!FILL) {
         for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_down(nmax, o, 64));
@@ -329,9 +331,16 @@ __device__ __forceinline__ bool air_has_z(const uint16_t* air_n, const uint2* ai
 }
 
 // FILL = false: seed_n only.  bbox = {imin, imax, jmin, jmax} of the columns that own a seed.
+// ArrLayout: where column (i, j) sits in the air / seed arrays, and how many rows below row 0 and
+// above row nx - 1 they hold (rows of the neighbouring slabs; none at the ends of the domain).
+struct ArrLayout {
+    size_t stride, off; int rows_lo, rows_hi;
+    __device__ size_t at(const GridView& g, int i, int j) const { return (size_t)((long long)off + (long long)i * g.ny + j); }
+};
+
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_ald_seeds(GridView g, unsigned H0q, const uint16_t* __restrict__ air_n, const uint2* __restrict__ air,
-                                                   uint16_t* __restrict__ seed_n, uint2* __restrict__ seed, int planes, int* __restrict__ bbox,
+__global__ __launch_bounds__(256) void k_ald_seeds(GridView g, unsigned H0q, const uint16_t* __restrict__ air_n, const uint2* __restrict__ air, ArrLayout A,
+                                                   uint16_t* __restrict__ seed_n, uint2* __restrict__ seed, ArrLayout S, int planes, int* __restrict__ bbox,
                                                    int* __restrict__ flags, unsigned long long* __restrict__ total) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     int imin = 0x7fffffff, imax = -1, jmin = 0x7fffffff, jmax = -1, nmax = 0;      // reduced per wave before the atomics
@@ -341,34 +350,35 @@ __global__ __launch_bounds__(256) void k_ald_seeds(GridView g, unsigned H0q, con
         const int i = (int)(c / g.ny), j = (int)(c - (size_t)i * g.ny);
         int n = 0;
         auto push = [&](unsigned a, unsigned b) {
-            if (FILL && n < planes) seed[(size_t)n * g.N + c] = make_uint2(a, b);
+            if (FILL && n < planes) seed[(size_t)n * S.stride + S.off + c] = make_uint2(a, b);
             n++;
         };
+        const size_t ac = A.off + c;
         unsigned prev = 0;
         for (int k = 0; k < l; k++) {
             const uint32_t r = g.rec[(size_t)k * g.N + c];
             const unsigned z0 = prev, z1 = rec_z1(r);
             prev = z1;
             if (rec_hole(r) || rec_mat(r) < 3) continue;
-            if (air_has_z(air_n, air, g.N, c, z1) || z1 == H0q) push(z1, z1);                    // top face
-            if (z0 > 0 && air_has_z(air_n, air, g.N, c, z0)) push(z0, z0);                       // bottom face
+            if (air_has_z(air_n, air, A.stride, ac, z1) || z1 == H0q) push(z1, z1);                    // top face
+            if (z0 > 0 && air_has_z(air_n, air, A.stride, ac, z0)) push(z0, z0);                       // bottom face
             const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
 #pragma unroll
             for (int d = 0; d < 4; d++) {                                                       // side faces
                 const int ni = i + di[d], nj = j + dj[d];
-                if (ni < 0 || nj < 0 || ni >= g.nx || nj >= g.ny) continue;
+                if (ni < -A.rows_lo || nj < 0 || ni >= g.nx + A.rows_hi || nj >= g.ny) continue;
                 if (z1 <= z0) continue;                                                         // intersectWith: v <= u + eps
-                const size_t nc = (size_t)ni * g.ny + nj;
+                const size_t nc = A.at(g, ni, nj);
                 const int na = air_n[nc];
                 for (int p = 0; p < na; p++) {
-                    const uint2 iv = air[(size_t)p * g.N + nc];
+                    const uint2 iv = air[(size_t)p * A.stride + nc];
                     if (iv.y <= z0) continue;
                     if (iv.x >= z1) break;
                     push(max(iv.x, z0), min(iv.y, z1));
                 }
             }
         }
-        if (!FILL) { seed_n[c] = (uint16_t)min(n, 65535); nmax = max(nmax, n); nsum += (unsigned long long)n; }
+        if (!FILL) { seed_n[S.off + c] = (uint16_t)min(n, 65535); nmax = max(nmax, n); nsum += (unsigned long long)n; }
         else if (n > 0) { imin = min(imin, i); imax = max(imax, i); jmin = min(jmin, j); jmax = max(jmax, j); }
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -440,7 +450,7 @@ struct AldTap { int du, dv; double add; };
 // --- coat at thickness t (computeCoatBitsSingleT + applyCoatFromBits, cg2:699-707, 585-682) --
 // bbox = the seeds' bounding box grown by the kernel radius and clipped to the domain (cg2:510-524).
 __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, const AldTap* __restrict__ taps, int ntaps,
-                           const uint16_t* __restrict__ seed_n, const uint2* __restrict__ seed, int seed_planes,
+                           const uint16_t* __restrict__ seed_n, const uint2* __restrict__ seed, int seed_planes, ArrLayout S,
                            int imin, int imax, int jmin, int jmax, int mat, int* __restrict__ flags) {
     extern __shared__ uint32_t lds[];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -452,12 +462,12 @@ __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, con
         if (i >= imin && i <= imax && j >= jmin && j <= jmax)
             for (int t = 0; t < ntaps; t++) {
                 const int si = i - taps[t].du, sj = j - taps[t].dv;
-                if (si < 0 || sj < 0 || si >= s.nx || sj >= s.ny) continue;
-                const size_t sc = (size_t)si * s.ny + sj;
+                if (si < -S.rows_lo || sj < 0 || si >= s.nx + S.rows_hi || sj >= s.ny) continue;
+                const size_t sc = S.at(s, si, sj);
                 const int ns = min((int)seed_n[sc], seed_planes);
                 const double add = taps[t].add;
                 for (int q = 0; q < ns; q++) {                 // cg2:542-557
-                    const uint2 sd = seed[(size_t)q * s.N + sc];
+                    const uint2 sd = seed[(size_t)q * S.stride + sc];
                     const double lo = (double)sd.x * s.zs - add, hi = (double)sd.y * s.zs + add;
                     if (hi <= lo + CG_EPS) continue;
                     const double z0 = lo > 0 ? lo : 0, z1 = hi < Hcap ? hi : Hcap;

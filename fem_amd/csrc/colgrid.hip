@@ -132,6 +132,9 @@ struct cg_grid {
     // deposit_ALD: seeds of the exposed faces (plane-major like the grid), their bounding box, the tap table
     uint16_t* seed_n = nullptr; uint2* seed = nullptr; int seed_planes = 0; bool has_seeds = false;
     int seed_bbox[4] = {0, -1, 0, -1}; uint64_t seed_total = 0;
+    // a slab also holds the seeds of seed_rows rows of each neighbour: column (i, j) is entry seed_off + i*ny + j,
+    // planes are seed_stride entries apart (a whole grid: seed_off = 0, seed_stride = N, no neighbour rows)
+    size_t seed_stride = 0, seed_off = 0; int seed_rows = 0; bool seed_lo = false, seed_hi = false;
     int* d_bbox = nullptr;
     uint8_t* cand = nullptr;                               // strip_connected: columns that still hold an unmarked node
     AldTap* d_ald_taps = nullptr; int ald_taps_cap = 0;
@@ -804,6 +807,11 @@ void drop_seeds(cg_grid* g) {
     if (g->seed) (void)hipFree(g->seed);
     g->seed_n = nullptr; g->seed = nullptr; g->seed_planes = 0; g->has_seeds = false; g->seed_total = 0;
     g->seed_bbox[0] = 0; g->seed_bbox[1] = -1; g->seed_bbox[2] = 0; g->seed_bbox[3] = -1;
+    g->seed_stride = g->seed_off = 0; g->seed_rows = 0; g->seed_lo = g->seed_hi = false;
+}
+
+ArrLayout seed_layout(const cg_grid* g) {
+    return ArrLayout{g->seed_stride, g->seed_off, g->seed_lo ? g->seed_rows : 0, g->seed_hi ? g->seed_rows : 0};
 }
 
 // buildKernelRows (script_columngrid2.js:466-496) flattened to (du, dv, add)
@@ -826,11 +834,13 @@ int build_ald_taps(const cg_grid* g, double t, std::vector<AldTap>* taps) {
 }
 
 // coat(t) from the held seeds, inserted as `mat`: the grid becomes grid + coat, spare set 0 keeps the grid as it was
-int ald_coat(cg_grid* g, int mat, double t) {
+// hmax_q: the height of the whole domain when the handle is a slab of it, null for the handle's own
+int ald_coat(cg_grid* g, int mat, double t, const uint32_t* hmax_q = nullptr) {
     if (!g->has_seeds) return fail(g, CG_ERR_STATE, "deposit_ALD: no seeds held (cg_ald_collect_seeds first)");
     unsigned qtop = 0;
     int rc = ensure_whole(g); if (rc) return rc;
     rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    if (hmax_q) qtop = *hmax_q;
     const double Hnow = qtop > 0 ? (double)qtop * g->zscale : 1.0;                               // maxHeight()
     const double Hcap = Hnow + t + g->zscale;                                                    // cg2:501, 702
     const AldLayout L = make_bit_layout(g, Hcap);
@@ -859,7 +869,7 @@ int ald_coat(cg_grid* g, int mat, double t) {
     ProfScope ps(g, CG_K_OTHER);
     return run_out_of_place(g, 0, "deposit_ALD", [&](GridView dst) {
         hipLaunchKernelGGL(k_ald_coat, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), dst, L, Hcap, g->d_ald_taps, ntaps,
-                           g->seed_n, g->seed, g->seed_planes, imin, imax, jmin, jmax, mat, g->d_flags);
+                           g->seed_n, g->seed, g->seed_planes, seed_layout(g), imin, imax, jmin, jmax, mat, g->d_flags);
     });
 }
 
@@ -1474,51 +1484,76 @@ int cg_etch_wet(cg_grid* g, int mat, double total_thickness, double dt) {
 }
 
 // ---- deposit_ALD (script_columngrid2.js:111-868) -----------------------------------------------
-int cg_ald_collect_seeds(cg_grid* g, double total_thickness, uint64_t* count) {
-    NEED(g);
-    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD on a slab of a decomposed domain is not built yet");
+namespace {
+// collectALDSeeds (cg2:405-463).  A slab passes the height of the whole domain, one boundary row of each
+// neighbour as ghost columns (their air decides the side faces of its own boundary rows), and
+// the number of neighbour rows to leave room for in the seed arrays.
+int collect_seeds(cg_grid* g, double total_thickness, const uint32_t* hmax_q, int planes, const void* ghost_lower, const void* ghost_upper,
+                  int halo_rows, uint64_t* count) {
     if (!(total_thickness > 0)) return fail(g, CG_ERR_ARG, "deposit_ALD thickness %g", total_thickness);
     unsigned qtop = 0;
     int rc = ensure_whole(g); if (rc) return rc;
     rc = refresh_len_bound(g, &qtop); if (rc) return rc;
+    if (hmax_q) qtop = *hmax_q;
     const double H0 = qtop > 0 ? (double)qtop * g->zscale : 1.0;
     const AldLayout L = make_bit_layout(g, H0 + total_thickness + g->zscale);                    // cg2:408
     size_t lds = 0;
     const int bt = ald_block(L, 1, &lds);
     if (!bt) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: %d height bins per column do not fit the bitsets", L.Zmax);
     drop_seeds(g);
+    const size_t ny = (size_t)g->ny;
+    // air: one row below and one above the slab; seeds: halo_rows rows on each side
+    const ArrLayout A{g->N + (hmax_q ? 2 * ny : 0), hmax_q ? ny : 0, ghost_lower ? 1 : 0, ghost_upper ? 1 : 0};
+    g->seed_rows = halo_rows; g->seed_lo = ghost_lower != nullptr; g->seed_hi = ghost_upper != nullptr;
+    g->seed_stride = g->N + 2 * (size_t)halo_rows * ny; g->seed_off = (size_t)halo_rows * ny;
+    const ArrLayout S = seed_layout(g);
+    GridView ghosts[2]; size_t ghost_off[2]; int nghost = 0;
+    for (int side = 0; side < 2; side++) {
+        const void* gp = side ? ghost_upper : ghost_lower;
+        if (!gp) continue;
+        GridView v = view(g);
+        v.nx = 1; v.N = ny; v.lmax = planes; v.split = 0;
+        v.len = (uint8_t*)const_cast<void*>(gp); v.rec = (uint32_t*)((uint8_t*)const_cast<void*>(gp) + ghost_len_bytes(g));
+        ghosts[nghost] = v; ghost_off[nghost] = side ? A.off + g->N : 0; nghost++;
+    }
     ProfScope ps(g, CG_K_OTHER);
     uint16_t* air_n = nullptr; uint2* air = nullptr;
     auto cleanup = [&]() { if (air_n) (void)hipFree(air_n); if (air) (void)hipFree(air); };
     auto body = [&]() -> int {
         int fl[4];
-        HIPCHK(g, hipMalloc(&air_n, std::max<size_t>(2 * g->N, 4)));
+        HIPCHK(g, hipMalloc(&air_n, std::max<size_t>(2 * A.stride, 4)));
+        HIPCHK(g, hipMemsetAsync(air_n, 0, std::max<size_t>(2 * A.stride, 4), g->stream));
         HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
-        hipLaunchKernelGGL(k_ald_air<false>, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), L, air_n, (uint2*)nullptr, 0, g->d_flags);
+        hipLaunchKernelGGL(k_ald_air<false>, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), L, air_n, (uint2*)nullptr, 0, A.stride, A.off, g->d_flags);
+        for (int k = 0; k < nghost; k++)
+            hipLaunchKernelGGL(k_ald_air<false>, dim3(ald_blocks(ny, bt)), dim3(bt), lds, g->stream, ghosts[k], L, air_n, (uint2*)nullptr, 0, A.stride, ghost_off[k], g->d_flags);
         HIPCHK(g, hipGetLastError());
         int r = read_flags(g, fl); if (r) return r;
         const int air_planes = std::max(1, fl[3]);
         if (air_planes > 65535) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: more than 65535 air intervals in a column");
-        HIPCHK(g, hipMalloc(&air, (size_t)air_planes * g->N * sizeof(uint2)));
-        hipLaunchKernelGGL(k_ald_air<true>, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), L, air_n, air, air_planes, g->d_flags);
+        HIPCHK(g, hipMalloc(&air, (size_t)air_planes * A.stride * sizeof(uint2)));
+        hipLaunchKernelGGL(k_ald_air<true>, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), L, air_n, air, air_planes, A.stride, A.off, g->d_flags);
+        for (int k = 0; k < nghost; k++)
+            hipLaunchKernelGGL(k_ald_air<true>, dim3(ald_blocks(ny, bt)), dim3(bt), lds, g->stream, ghosts[k], L, air_n, air, air_planes, A.stride, ghost_off[k], g->d_flags);
         HIPCHK(g, hipGetLastError());
         // seeds: count, then fill
         const unsigned H0q = qtop > 0 ? qtop : 0xFFFFFFFFu;                                      // |z1 - maxHeight()| < eps (cg2:440)
-        HIPCHK(g, hipMalloc(&g->seed_n, std::max<size_t>(2 * g->N, 4)));
+        HIPCHK(g, hipMalloc(&g->seed_n, std::max<size_t>(2 * S.stride, 4)));
+        HIPCHK(g, hipMemsetAsync(g->seed_n, 0, std::max<size_t>(2 * S.stride, 4), g->stream));    // neighbour rows: none until they arrive
         HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
         HIPCHK(g, hipMemsetAsync(g->d_sum, 0, sizeof(unsigned long long), g->stream));
         const dim3 grid(blocks_for(g->N)), blk(256);
-        hipLaunchKernelGGL(k_ald_seeds<false>, grid, blk, 0, g->stream, view(g), H0q, air_n, air, g->seed_n, (uint2*)nullptr, 0, g->d_bbox, g->d_flags, g->d_sum);
+        hipLaunchKernelGGL(k_ald_seeds<false>, grid, blk, 0, g->stream, view(g), H0q, air_n, air, A, g->seed_n, (uint2*)nullptr, S, 0, g->d_bbox, g->d_flags, g->d_sum);
         HIPCHK(g, hipGetLastError());
         r = read_flags(g, fl); if (r) return r;
         unsigned long long total = 0;
         HIPCHK(g, hipMemcpy(&total, g->d_sum, sizeof total, hipMemcpyDeviceToHost));
         if (fl[3] > 65535) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: more than 65535 seeds in a column");
         g->seed_planes = std::max(1, fl[3]);
-        HIPCHK(g, hipMalloc(&g->seed, (size_t)g->seed_planes * g->N * sizeof(uint2)));
+        HIPCHK(g, hipMalloc(&g->seed, (size_t)g->seed_planes * S.stride * sizeof(uint2)));
         const int bb0[4] = {INT32_MAX, -1, INT32_MAX, -1};
         HIPCHK(g, hipMemcpyAsync(g->d_bbox, bb0, sizeof bb0, hipMemcpyHostToDevice, g->stream));
-        hipLaunchKernelGGL(k_ald_seeds<true>, grid, blk, 0, g->stream, view(g), H0q, air_n, air, g->seed_n, g->seed, g->seed_planes, g->d_bbox, g->d_flags, g->d_sum);
+        hipLaunchKernelGGL(k_ald_seeds<true>, grid, blk, 0, g->stream, view(g), H0q, air_n, air, A, g->seed_n, g->seed, S, g->seed_planes, g->d_bbox, g->d_flags, g->d_sum);
         HIPCHK(g, hipGetLastError());
         HIPCHK(g, hipMemcpyAsync(g->seed_bbox, g->d_bbox, sizeof bb0, hipMemcpyDeviceToHost, g->stream));
         HIPCHK(g, hipStreamSynchronize(g->stream));
@@ -1530,6 +1565,82 @@ int cg_ald_collect_seeds(cg_grid* g, double total_thickness, uint64_t* count) {
     cleanup();
     if (rc) { drop_seeds(g); return rc; }
     if (count) *count = g->seed_total;
+    return CG_OK;
+}
+
+// seeds of a neighbour's rows on the wire: counts u16[rows*ny] (padded to 8 bytes), then seeds uint2[planes][rows*ny]
+size_t seed_halo_count_bytes(const cg_grid* g) { return (2 * (size_t)g->seed_rows * g->ny + 7) & ~(size_t)7; }
+}  // namespace
+
+int cg_ald_collect_seeds(cg_grid* g, double total_thickness, uint64_t* count) {
+    NEED(g);
+    if (g->nx != g->nx_global)
+        return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD on a slab needs its neighbours' boundary rows and the whole domain's height: use cg_ald_collect_seeds_slab");
+    return collect_seeds(g, total_thickness, nullptr, 0, nullptr, nullptr, 0, count);
+}
+
+int cg_ald_collect_seeds_slab(cg_grid* g, double total_thickness, uint32_t hmax_q, int planes, const void* ghost_lower, const void* ghost_upper,
+                              int* seed_planes, uint64_t* count) {
+    NEED(g);
+    if (planes < 0 || planes > 256) return fail(g, CG_ERR_ARG, "bad ghost plane count %d", planes);
+    if (!(total_thickness > 0)) return fail(g, CG_ERR_ARG, "deposit_ALD thickness %g", total_thickness);
+    const int rows = js_to_int32(std::ceil(total_thickness / g->dx));                            // the widest coat's reach in rows (cg2:467)
+    if ((ghost_lower || ghost_upper) && rows > g->nx)
+        return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: a coat of %g nm reaches %d rows, the slab has %d", total_thickness, rows, g->nx);
+    int rc = collect_seeds(g, total_thickness, &hmax_q, planes, ghost_lower, ghost_upper, rows, count); if (rc) return rc;
+    if (seed_planes) *seed_planes = g->seed_planes;
+    return CG_OK;
+}
+
+int cg_ald_seed_halo_bytes(const cg_grid* g, int seed_planes, size_t* bytes) {
+    if (!g || !bytes || seed_planes < 1 || !g->has_seeds) return CG_ERR_ARG;
+    *bytes = seed_halo_count_bytes(g) + (size_t)seed_planes * g->seed_rows * g->ny * sizeof(uint2);
+    return CG_OK;
+}
+
+int cg_ald_seed_halo_pack(cg_grid* g, int seed_planes, void* send_lower, void* send_upper) {
+    NEED(g);
+    if (!g->has_seeds) return fail(g, CG_ERR_STATE, "deposit_ALD: no seeds held (cg_ald_collect_seeds_slab first)");
+    if (seed_planes < g->seed_planes || seed_planes > 65535 || !send_lower || !send_upper)
+        return fail(g, CG_ERR_ARG, "bad seed exchange arguments (%d planes asked, %d held)", seed_planes, g->seed_planes);
+    if (seed_planes > g->seed_planes) {                        // a neighbour's columns hold more seeds than any of ours
+        uint2* bigger = nullptr;
+        HIPCHK(g, hipMalloc(&bigger, (size_t)seed_planes * g->seed_stride * sizeof(uint2)));
+        HIPCHK(g, hipMemsetAsync(bigger, 0, (size_t)seed_planes * g->seed_stride * sizeof(uint2), g->stream));
+        HIPCHK(g, hipMemcpyAsync(bigger, g->seed, (size_t)g->seed_planes * g->seed_stride * sizeof(uint2), hipMemcpyDeviceToDevice, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        (void)hipFree(g->seed);
+        g->seed = bigger; g->seed_planes = seed_planes;
+    }
+    const size_t n = (size_t)g->seed_rows * g->ny, cb = seed_halo_count_bytes(g);
+    if (n == 0) return CG_OK;
+    const size_t first[2] = {g->seed_off, g->seed_off + g->N - n};       // our first rows go down, our last rows go up
+    void* out[2] = {send_lower, send_upper};
+    for (int side = 0; side < 2; side++) {
+        HIPCHK(g, hipMemcpyAsync(out[side], g->seed_n + first[side], 2 * n, hipMemcpyDeviceToDevice, g->stream));
+        HIPCHK(g, hipMemcpy2DAsync((uint8_t*)out[side] + cb, n * sizeof(uint2), g->seed + first[side], g->seed_stride * sizeof(uint2),
+                                   n * sizeof(uint2), (size_t)seed_planes, hipMemcpyDeviceToDevice, g->stream));
+    }
+    return CG_OK;
+}
+
+int cg_ald_seed_halo_unpack(cg_grid* g, int seed_planes, const void* recv_lower, const void* recv_upper) {
+    NEED(g);
+    if (!g->has_seeds) return fail(g, CG_ERR_STATE, "deposit_ALD: no seeds held (cg_ald_collect_seeds_slab first)");
+    if (seed_planes != g->seed_planes) return fail(g, CG_ERR_ARG, "seed exchange of %d planes, %d held (pack first)", seed_planes, g->seed_planes);
+    if ((recv_lower != nullptr) != g->seed_lo || (recv_upper != nullptr) != g->seed_hi)
+        return fail(g, CG_ERR_ARG, "seed rows must come from the sides the ghost columns came from");
+    const size_t n = (size_t)g->seed_rows * g->ny, cb = seed_halo_count_bytes(g);
+    const size_t first[2] = {0, g->seed_off + g->N};                     // the rows below row 0, the rows above the last
+    const void* in[2] = {recv_lower, recv_upper};
+    for (int side = 0; side < 2 && n > 0; side++) {
+        if (!in[side]) continue;
+        HIPCHK(g, hipMemcpyAsync(g->seed_n + first[side], in[side], 2 * n, hipMemcpyDeviceToDevice, g->stream));
+        HIPCHK(g, hipMemcpy2DAsync(g->seed + first[side], g->seed_stride * sizeof(uint2), (const uint8_t*)in[side] + cb, n * sizeof(uint2),
+                                   n * sizeof(uint2), (size_t)seed_planes, hipMemcpyDeviceToDevice, g->stream));
+    }
+    // a neighbour's seed may reach any of our columns: the coat looks at every column of the slab
+    g->seed_bbox[0] = 0; g->seed_bbox[1] = g->nx - 1; g->seed_bbox[2] = 0; g->seed_bbox[3] = g->ny - 1;
     return CG_OK;
 }
 
@@ -1549,11 +1660,19 @@ int cg_ald_drop_seeds(cg_grid* g) {
 
 int cg_ald_coat(cg_grid* g, int mat, double t) {
     NEED(g);
-    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD on a slab of a decomposed domain is not built yet");
+    if (g->nx != g->nx_global) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD on a slab needs the whole domain's height: use cg_ald_coat_slab");
     if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
     if (!(t > 0)) return fail(g, CG_ERR_ARG, "deposit_ALD coat thickness %g", t);
     g->pend.active = false;
     return ald_coat(g, mat, t);
+}
+
+int cg_ald_coat_slab(cg_grid* g, int mat, double t, uint32_t hmax_q) {
+    NEED(g);
+    if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
+    if (!(t > 0)) return fail(g, CG_ERR_ARG, "deposit_ALD coat thickness %g", t);
+    g->pend.active = false;
+    return ald_coat(g, mat, t, &hmax_q);
 }
 
 int cg_ald_increment(cg_grid* g, int mat, double t) {
@@ -1571,6 +1690,16 @@ int cg_ald_increment(cg_grid* g, int mat, double t) {
         qtop_base = r[0];
     }
     rc = cg_identify_cavity(g); if (rc) return rc;                      // cg2:851
+    return cg_ald_merge_slab(g, qtop_base);
+}
+
+// mergeNewCavityFromTmp (cg2:766-814): the grid holds coat + cavities, spare set 0 the state before the coat,
+// hbase_q the height of that state over the whole domain.
+int cg_ald_merge_slab(cg_grid* g, uint32_t hbase_q) {
+    NEED(g);
+    if (!g->alt_rec[0]) return fail(g, CG_ERR_STATE, "deposit_ALD: no state from before a coat is held");
+    int rc = ensure_whole(g); if (rc) return rc;
+    const unsigned qtop_base = hbase_q;
     const double Hbase = qtop_base > 0 ? (double)qtop_base * g->zscale : 1.0;
     const AldLayout L = make_bit_layout(g, Hbase + g->zscale);
     size_t lds = 0;

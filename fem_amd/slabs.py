@@ -201,6 +201,52 @@ class SlabGrid:
         self.identify_cavity()                                                                # cg3:307
         g.release_scratch()
 
+    def _seed_buffers(self, nbytes):
+        if getattr(self, "_seedbuf", None) is None or self._seedbuf[0].numel() < nbytes:
+            self._seedbuf = [torch.zeros(max(nbytes, 8), dtype=torch.uint8, device=self.device) for _ in range(4)]
+        s_lo, s_up, r_lo, r_up = [t.data_ptr() for t in self._seedbuf]
+        return s_lo, s_up, (r_lo if self.has_lower else 0), (r_up if self.has_upper else 0)
+
+    def deposit_ALD(self, matId, totalThk, dt=None):
+        """deposit_ALD(matId, totalThk, {dt}) (script_columngrid2.js:111-868) over all slabs, without the
+        slider cache.  The seeds are collected once from the grid as it stands (cg2:826), so the slabs
+        exchange once: a ghost row per side for the side faces of the boundary rows, then the seeds of
+        the ceil(totalThk/dx) rows next to each edge, which every later coat reads.  Each increment
+        then needs the whole domain's height and the cavity pass over all slabs, nothing else."""
+        if self.world == 1:
+            return self.grid.deposit_ALD(matId, totalThk, dt=dt)
+        g = self.grid
+        T = 0.0 if totalThk != totalThk else max(0.0, float(totalThk))                       # cg2:112-113
+        if T <= 0:
+            return
+        step = max(max(self.dx, self.dy, min(self.dx, self.dy)) if dt is None else float(dt), 1e-3)   # cg2:124-127
+        _, _, max_len, top_q = g.cavity_state()
+        planes, hmax_q = self._reduce_max([max_len, top_q])
+        nbytes, s_lo, s_up, lo, up = self._ghost_buffers(planes)
+        g.ghost_pack(planes, s_lo, s_up); g.sync(); self._swap_ghosts(nbytes)
+        seed_planes = self._reduce_max([g.ald_collect_seeds_slab(T, hmax_q, planes, lo, up)])[0]
+        nbytes = g.ald_seed_halo_bytes(seed_planes)
+        s_lo, s_up, lo, up = self._seed_buffers(nbytes)
+        g.ald_seed_halo_pack(seed_planes, s_lo, s_up); g.sync()
+        self.comm.swap(*[t[:nbytes] for t in self._seedbuf])
+        g.ald_seed_halo_unpack(seed_planes, lo, up); g.sync()
+        try:
+            t = step
+            while t < T - 1e-9:                                                               # cg2:843-858
+                hbase_q = self._reduce_max([g.cavity_state()[3]])[0]
+                g.ald_coat_slab(matId, t, hbase_q)
+                self._gaps_anywhere = None
+                self.identify_cavity()                                                        # cg2:851
+                g.ald_merge_slab(hbase_q)
+                self._gaps_anywhere = None
+                t += step
+            g.ald_coat_slab(matId, T, self._reduce_max([g.cavity_state()[3]])[0])             # cg2:861-862
+            self._gaps_anywhere = None
+            self.identify_cavity()                                                            # cg2:867
+        finally:
+            g.release_scratch()
+            g.ald_drop_seeds()
+
     def identify_cavity(self):
         """identify_cavity() (script_columngrid2.js:9-83) over all slabs."""
         if self.world == 1:

@@ -232,6 +232,29 @@ int cg_ald_drop_seeds(cg_grid* g);
 int cg_ald_increment(cg_grid* g, int mat, double t);
 int cg_ald_coat(cg_grid* g, int mat, double t);
 
+/* deposit_ALD on a slab of a decomposed domain (no counterpart in the reference, which is
+ * single-threaded).  The seeds are collected once (cg2:826), so the slabs talk once:
+ *   cg_ald_collect_seeds_slab  collectALDSeeds for the slab's own rows.  The caller has packed and
+ *                         swapped one ghost row per side (cg_ghost_pack, `planes` = the largest
+ *                         column of any slab; null = the domain ends there) and passes the whole
+ *                         domain's quantised maximum height.  *seed_planes = most seeds in one of
+ *                         the slab's columns; the caller takes the maximum over the slabs.
+ *   cg_ald_seed_halo_*    the seeds of the slab's first / last ceil(total/dx) rows as messages for
+ *                         the lower / upper neighbour (counts u16[rows*ny] padded to 8 bytes, then
+ *                         (zA, zB) u32 pairs [seed_planes][rows*ny]), and the neighbours' messages
+ *                         into the handle.  Device pointers; pack, swap, unpack.
+ *   cg_ald_coat_slab      cg_ald_coat against the whole domain's height (cg2:501).
+ *   cg_ald_merge_slab     mergeNewCavityFromTmp (cg2:766-814) after the cavity pass over all slabs
+ *                         (cg_cavity_state / cg_cavity_fill / cg_strip_*); hbase_q = the whole
+ *                         domain's height before the coat, i.e. what cg_ald_coat_slab was given. */
+int cg_ald_collect_seeds_slab(cg_grid* g, double total_thickness, uint32_t hmax_q, int planes,
+                              const void* ghost_lower, const void* ghost_upper, int* seed_planes, uint64_t* count);
+int cg_ald_seed_halo_bytes(const cg_grid* g, int seed_planes, size_t* bytes);
+int cg_ald_seed_halo_pack(cg_grid* g, int seed_planes, void* send_lower, void* send_upper);
+int cg_ald_seed_halo_unpack(cg_grid* g, int seed_planes, const void* recv_lower, const void* recv_upper);
+int cg_ald_coat_slab(cg_grid* g, int mat, double t, uint32_t hmax_q);
+int cg_ald_merge_slab(cg_grid* g, uint32_t hbase_q);
+
 /* Frees the second and third set of planes that etch_wet / deposit_ALD steps work in
  * (they are as large as the grid itself).  No counterpart in the reference. */
 int cg_release_scratch(cg_grid* g);

@@ -24,7 +24,7 @@ else:
 rank, world = dist.get_rank(), dist.get_world_size()
 nxl, ny = 64, 96
 nxg = nxl * world
-for name in ("c4", "cs", "cwet"):
+for name in ("c4", "cs", "cwet", "cw"):
     flow = flows.FLOWS[name]()
     specs = flows.mask_specs(2.0 * nxg)
     o = OracleGrid(2.0 * nxg, 2.0 * ny, 2.0, 2.0)

@@ -674,7 +674,7 @@ class _ThreadComm:
         return _Rank()
 
 
-@pytest.mark.parametrize("parts,flow_name", [(2, "cs"), (3, "cs"), (3, "c4"), (2, "cwet"), (3, "cwet")])
+@pytest.mark.parametrize("parts,flow_name", [(2, "cs"), (3, "cs"), (3, "c4"), (2, "cwet"), (3, "cwet"), (2, "cw"), (3, "cw")])
 def test_slab_driver_on_one_gpu(parts, flow_name):
     """fem_amd.slabs.SlabGrid itself (halo rows, all-reduced scalars, ghost-row flood of STRIP /
     identify_cavity, CMP) with P slabs driven by P threads on one device: the summed checksum equals

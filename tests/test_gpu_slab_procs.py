@@ -16,4 +16,4 @@ def test_two_processes_one_gpu():
            "--master-addr", "127.0.0.1", "--master-port", "29647", os.path.join(HERE, "dist_gpu_slab_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert all(f"slab flow {n} ok on 2 ranks" in r.stdout for n in ("c4", "cs", "cwet"))
+    assert all(f"slab flow {n} ok on 2 ranks" in r.stdout for n in ("c4", "cs", "cwet", "cw"))
