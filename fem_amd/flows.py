@@ -172,7 +172,7 @@ def flow_cw():
 
 def flow_cwet():
     """Not a benchmark configuration: WETETCH undercuts between lateral steps, STRIP and CMP, for the
-    parity tests of the slab driver (which runs etch_wet across slab edges, deposit_ALD not)."""
+    parity tests of the slab driver (etch_wet across slab edges without deposit_ALD in between)."""
     return [
         _s("SUBSTR", None, SI, 30), _s("DEPO", None, OX, 8), _s("DEPO", None, NIT, 12),
         _s("ETCH", "M", ALL, 26), _s("WETETCH", None, OX, 5), _s("DEPO", None, M6, 3, 1.0),

@@ -76,6 +76,9 @@ def _lib():
     L.og_slider_wet_entries.argtypes = [vp]
     L.og_slider_seed_count.restype = C.c_size_t; L.og_slider_seed_count.argtypes = [vp]
     L.og_ald_taps.argtypes = [vp, d, vp, vp, vp]
+    L.og_ald_seeds_part.restype = C.c_size_t; L.og_ald_seeds_part.argtypes = [vp, d, d, vp, vp, vp, vp, C.c_size_t]
+    L.og_ald_coat_part.argtypes = [vp, i, d, d, vp, vp, vp, vp, C.c_size_t]
+    L.og_ald_merge_part.argtypes = [vp, d, vp, vp, vp, i]
     return L
 
 
@@ -197,6 +200,28 @@ class OracleGrid:
 
     def max_height(self):
         return self.L.og_max_height(self.h)
+
+    # deposit_ALD in the pieces one slab of a larger domain runs; h_nm = the whole domain's height
+    def ald_seeds_part(self, T, h_nm):
+        """-> (i, j, zAq, zBq) arrays of the seeds collectALDSeeds finds on this grid."""
+        n = self.L.og_ald_seeds_part(self.h, T, h_nm, None, None, None, None, 0)
+        si = np.zeros(max(n, 1), np.int32); sj = np.zeros(max(n, 1), np.int32)
+        za = np.zeros(max(n, 1), np.uint32); zb = np.zeros(max(n, 1), np.uint32)
+        self.L.og_ald_seeds_part(self.h, T, h_nm, _ptr(si), _ptr(sj), _ptr(za), _ptr(zb), n)
+        return si[:n], sj[:n], za[:n], zb[:n]
+
+    def ald_coat_part(self, mat, t, h_nm, si, sj, za, zb):
+        si = np.ascontiguousarray(si, np.int32); sj = np.ascontiguousarray(sj, np.int32)
+        za = np.ascontiguousarray(za, np.uint32); zb = np.ascontiguousarray(zb, np.uint32)
+        rc = self.L.og_ald_coat_part(self.h, int(mat), float(t), float(h_nm), _ptr(si), _ptr(sj), _ptr(za), _ptr(zb), si.size)
+        if rc:
+            raise RuntimeError("the reference throws here (deposit_ALD coat rc=%d)" % rc)
+
+    def ald_merge_part(self, hbase_nm, ln, mat, zp, lmax):
+        ln = np.ascontiguousarray(ln, np.uint8); mat = np.ascontiguousarray(mat, np.uint8); zp = np.ascontiguousarray(zp, np.uint16)
+        rc = self.L.og_ald_merge_part(self.h, float(hbase_nm), _ptr(ln), _ptr(mat), _ptr(zp), int(lmax))
+        if rc:
+            raise RuntimeError("the reference throws here (deposit_ALD merge rc=%d)" % rc)
 
     def checksum(self):
         return self.L.og_checksum(self.h)

@@ -160,6 +160,109 @@ class OracleSlabEngine:
     def release_scratch(self):
         pass
 
+    # ---- deposit_ALD in the pieces the slab driver calls ---------------------------------------
+    def _with_rows(self, below, above, lo=None, up=None):
+        """A scratch grid = `below` rows, the slab's own rows, `above` rows; lo / up = ghost columns for
+        the single row next to the slab (else the extra rows are empty).  -> (grid, first own column, end)."""
+        ln, mat, zp, L = self._layers()
+        rows = below + self.nx + above
+        Lx = max(L, max([len(c) for g_ in (lo, up) if g_ is not None for c in g_] + [1]))
+        eln = np.zeros(rows * self.ny, np.uint8); emat = np.zeros((rows * self.ny, Lx), np.uint8)
+        ezp = np.zeros((rows * self.ny, Lx, 2), np.uint16)
+
+        def put_ghost(cols, row):
+            for j, lay in enumerate(cols):
+                c = row * self.ny + j; eln[c] = len(lay)
+                for k, (z0, z1, m, _) in enumerate(lay):
+                    emat[c, k] = m; ezp[c, k] = (z0, z1)
+        if lo is not None:
+            put_ghost(lo, below - 1)
+        a, b = below * self.ny, (below + self.nx) * self.ny
+        eln[a:b] = ln; emat[a:b, :L] = mat; ezp[a:b, :L] = zp
+        if up is not None:
+            put_ghost(up, below + self.nx)
+        scratch = OracleGrid(dx=self.dx, dy=self.dy, slab=(rows, self.ny, 0, rows), lmax=Lx)
+        scratch.upload(eln, emat.reshape(-1), ezp.reshape(-1), Lx)
+        return scratch, a, b
+
+    def _keep_own(self, scratch, a, b):
+        sl, sm, sz = scratch.arrays(); Ls = scratch.Lmax
+        self.o.upload(sl[a:b], sm.reshape(-1, Ls)[a:b].reshape(-1), sz.reshape(-1, Ls, 2)[a:b].reshape(-1), Ls)
+
+    @staticmethod
+    def _height_nm(q):
+        return q * 0.1 if q > 0 else 1.0                      # maxHeight() is 1 on an empty grid
+
+    def ald_collect_seeds_slab(self, T, hmax_q, planes, ghost_lower, ghost_upper):
+        lo, up = self._ghost_columns(planes, ghost_lower), self._ghost_columns(planes, ghost_upper)
+        below = 1 if lo is not None else 0
+        scratch, a, b = self._with_rows(below, 1 if up is not None else 0, lo, up)
+        si, sj, za, zb = scratch.ald_seeds_part(float(T), self._height_nm(int(hmax_q)))
+        si = si - below
+        own = (si >= 0) & (si < self.nx)                      # the ghost rows' own seeds are their slabs' business
+        self._seed_rows = int(math.ceil(T / self.dx))
+        self._seed_sides = (lo is not None, up is not None)
+        self._seeds = [np.stack([si[own], sj[own], za[own].astype(np.int64), zb[own].astype(np.int64)], 1).astype(np.int64)]
+        per_col = np.bincount(si[own] * self.ny + sj[own], minlength=self.nx * self.ny)
+        return max(1, int(per_col.max()) if per_col.size else 1)
+
+    def _seed_halo_layout(self, seed_planes):
+        n = self._seed_rows * self.ny
+        cb = (2 * n + 7) & ~7
+        return n, cb, cb + seed_planes * n * 8
+
+    def ald_seed_halo_bytes(self, seed_planes):
+        return self._seed_halo_layout(seed_planes)[2]
+
+    def ald_seed_halo_pack(self, seed_planes, send_lower, send_upper):
+        n, cb, nb = self._seed_halo_layout(seed_planes)
+        R = self._seed_rows
+        own = self._seeds[0]
+        for ptr, first in ((send_lower, 0), (send_upper, self.nx - R)):
+            buf = _view(ptr, nb); buf[:] = 0
+            cnt = buf[:2 * n].view(np.uint16)
+            sd = buf[cb:].view(np.uint32).reshape(seed_planes, n, 2)
+            for i, j, za, zb in own[(own[:, 0] >= first) & (own[:, 0] < first + R)]:
+                e = (i - first) * self.ny + j
+                sd[cnt[e], e] = (za, zb); cnt[e] += 1
+
+    def ald_seed_halo_unpack(self, seed_planes, recv_lower, recv_upper):
+        n, cb, nb = self._seed_halo_layout(seed_planes)
+        R = self._seed_rows
+        assert (bool(recv_lower), bool(recv_upper)) == self._seed_sides
+        del self._seeds[1:]
+        for ptr, first in ((recv_lower, -R), (recv_upper, self.nx)):
+            if not ptr:
+                continue
+            buf = _view(ptr, nb)
+            cnt = buf[:2 * n].view(np.uint16)
+            sd = buf[cb:].view(np.uint32).reshape(seed_planes, n, 2)
+            got = [(first + e // self.ny, e % self.ny, int(sd[q, e, 0]), int(sd[q, e, 1])) for e in range(n) for q in range(int(cnt[e]))]
+            if got:
+                self._seeds.append(np.array(got, np.int64))
+
+    def ald_coat_slab(self, matId, t, hmax_q):
+        """coat(t) on a scratch grid with room for the neighbours' seed rows; the slab keeps its own rows."""
+        R = self._seed_rows
+        ln, mat, zp, L = self._layers()
+        self._ald_base = (ln.astype(np.uint8), mat.copy(), zp.astype(np.uint16), L)
+        scratch, a, b = self._with_rows(R, R)
+        sd = np.concatenate(self._seeds, 0)
+        scratch.ald_coat_part(matId, t, self._height_nm(int(hmax_q)), sd[:, 0] + R, sd[:, 1], sd[:, 2], sd[:, 3])
+        self._keep_own(scratch, a, b)
+
+    def ald_merge_slab(self, hbase_q):
+        ln, mat, zp, L = self._ald_base
+        Ln = self.o.Lmax
+        if Ln > L:                                             # the cavity pass made the arrays wider: the base follows
+            m2 = np.zeros((ln.size, Ln), np.uint8); z2 = np.zeros((ln.size, Ln, 2), np.uint16)
+            m2[:, :L] = mat; z2[:, :L] = zp
+            mat, zp, L = m2, z2, Ln
+        self.o.ald_merge_part(self._height_nm(int(hbase_q)), ln, mat.reshape(-1), zp.reshape(-1), L)
+
+    def ald_drop_seeds(self):
+        self._seeds = None; self._ald_base = None
+
     _js_round = staticmethod(lambda x: math.floor(x + 0.5))
     zScale = 0.1
 
