@@ -38,19 +38,25 @@ def parse():
 
 
 def build_masks(fem, flows, grid, specs, names, nx, ny, i0, LX, LY, device):
-    """Device rasters for the masks a flow uses (periodic ones in closed form on the GPU)."""
+    """Device rasters for the masks a flow uses, made by the engine's rasteriser from the fabric-style
+    shape records of the reference (periodic masks: the shapes that reach this rank's rows), and checked
+    against the closed form of the periodic ones."""
     import torch
     out = {}
     for name in names:
         spec = specs[name]
         if spec["kind"] == "shapes":
             out[name] = grid.mask_from_shapes(fem.reduce_mask(spec["data"]))
-        else:
-            r = flows.raster_torch(spec, nx, ny, i0, device)
-            torch.cuda.current_stream().synchronize()
-            out[name] = grid.mask_from_device_raster(r.data_ptr(), r.numel())
-            grid.sync()
-            del r
+            continue
+        data = flows.shapes_of(spec, LX, LY, x_range=(2.0 * i0, 2.0 * (i0 + nx)))
+        out[name] = grid.mask_from_shapes(fem.reduce_mask(data))
+        del data
+        want = flows.raster_torch(spec, nx, ny, i0, device)
+        got = torch.from_numpy(out[name].download()).to(device)
+        same = bool((got == want).all())
+        del want, got
+        if not same:
+            raise RuntimeError(f"mask {name}: the rasterised shape list differs from the closed form")
     return out
 
 

@@ -8,9 +8,9 @@ runtime dispatches its process records (template/script_runtime.js:162-180): SUB
 
 Masks are given in nanometres so they scale with the domain.  Periodic masks have up to
 hundreds of thousands of identical shapes on the large grids; for those the raster is also
-available in closed form (integer arithmetic on the cell centres x = 2i+1, y = 2j+1), which is
-what the benchmark uses at full size.  `shapes_of` expands the same mask into the fabric-style
-object list the reference's predicate consumes, so small sizes can be checked against it.
+available in closed form (integer arithmetic on the cell centres x = 2i+1, y = 2j+1).  `shapes_of`
+expands the same mask into the fabric-style object list the reference's predicate consumes: the
+benchmark rasterises that list and checks the result against the closed form.
 """
 import numpy as np
 
@@ -49,8 +49,10 @@ def mask_specs(L_nm):
     }
 
 
-def shapes_of(spec, LX_nm, LY_nm):
-    """Expand a mask spec into the fabric-style JSON ({'objects': [...]}) the reference consumes."""
+def shapes_of(spec, LX_nm, LY_nm, x_range=None):
+    """Expand a mask spec into the fabric-style JSON ({'objects': [...]}) the reference consumes.
+    x_range = (x0, x1) in nm keeps only the shapes of a periodic mask that reach that band (what one slab
+    of a decomposed domain needs; they all have the same polarity, so leaving the others out changes nothing)."""
     if spec["kind"] == "shapes":
         return spec["data"]
     objs = []
@@ -58,12 +60,16 @@ def shapes_of(spec, LX_nm, LY_nm):
     if spec["kind"] == "periodic_rects":
         s, sh = spec["size"], spec["shift"]
         for x in range(sh, int(LX_nm), p):
+            if x_range is not None and (x + s < x_range[0] or x > x_range[1]):
+                continue
             for y in range(sh, int(LY_nm), p):
                 objs.append({"type": "rect", "left": x, "top": y, "width": s, "height": s, "angle": 0, "scaleX": 1,
                              "scaleY": 1, "visible": True, "data": {"polarity": "positive"}})
     elif spec["kind"] == "periodic_circles":
         r = spec["radius"]
         for x in range(0, int(LX_nm), p):
+            if x_range is not None and (x + 2 * r < x_range[0] or x > x_range[1]):
+                continue
             for y in range(0, int(LY_nm), p):
                 objs.append({"type": "circle", "left": x, "top": y, "radius": r, "width": 2 * r, "height": 2 * r, "angle": 0,
                              "scaleX": 1, "scaleY": 1, "visible": True, "data": {"polarity": "positive"}})

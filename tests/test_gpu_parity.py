@@ -127,6 +127,57 @@ def _random_mask_data(rng, L, nshapes):
     return {"objects": objs}
 
 
+@pytest.mark.parametrize("nshapes,slab", [(7, None), (300, None), (300, (70, 150)), (2500, None)])
+def test_mask_rasteriser_many_shapes(nshapes, slab):
+    """_isPointBlocked (script_runtime.js:54-141) with the shapes binned by tile (8 shapes or more) and walked
+    one by one (fewer): rectangles, circles, ellipses and polygons, rotated, scaled and mirrored, of both
+    polarities, some far larger than a tile, some off the grid; on a whole grid and on a slab of it."""
+    fem = _engine()
+    rng = _lcg(1000 + nshapes)
+    nx, ny = 290, 333
+    data = _random_mask_data(rng, 2 * max(nx, ny), nshapes)
+    for k, o in enumerate(data["objects"]):
+        if k % 5 == 1:
+            o["scaleX"], o["scaleY"] = [(0.4, 1.7), (-1.0, 1.0), (2.5, -0.6)][k % 3]
+        if k % 11 == 3:
+            o["left"] -= 3 * nx; o["width"] *= 6; o["height"] *= 5        # large, partly off the grid
+        if k % 17 == 4:
+            o["left"] += 5 * nx                                           # entirely off the grid
+        if nshapes > 1000:
+            o["width"] = 2 + o["width"] / 12; o["height"] = 2 + o["height"] / 12
+            if o["type"] == "circle":
+                o["radius"] = o["width"] / 2; o["height"] = o["width"]
+            if o["type"] == "ellipse":
+                o["rx"], o["ry"] = o["width"] / 2, o["height"] / 2
+    red = fem.reduce_mask(data)
+    want = OracleGrid(2 * nx, 2 * ny, 2, 2).mask_raster(red).reshape(nx, ny)
+    if slab is None:
+        g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    else:
+        g = fem.ColumnGrid(dx=2.0, dy=2.0, slab=(nx, ny, slab[0], slab[1]))
+        want = want[slab[0]:slab[0] + slab[1]]
+    got = g.mask_from_shapes(red).download()
+    assert 0 < int(want.sum()) < want.size
+    np.testing.assert_array_equal(got, want.reshape(-1))
+    g.close()
+
+
+def test_mask_rasteriser_periodic_at_scale():
+    """The benchmark's periodic masks as shape lists (16 384 squares, 29 584 discs on 4096 x 4096 columns)
+    against their closed form on the cell centres."""
+    fem = _engine()
+    from fem_amd import flows
+    n = 4096
+    specs = flows.mask_specs(2.0 * n)
+    g = fem.ColumnGrid(2.0 * n, 2.0 * n, 2, 2)
+    for name in ("M", "Mshift", "Mc"):
+        red = fem.reduce_mask(flows.shapes_of(specs[name], 2 * n, 2 * n))
+        m = g.mask_from_shapes(red)
+        np.testing.assert_array_equal(m.download(), flows.raster_numpy(specs[name], n, n), err_msg=name)
+        m.destroy()
+    g.close()
+
+
 @pytest.mark.parametrize("nx,ny,seed", [(192, 320, 1), (333, 257, 2), (512, 512, 3), (100, 90, 4)])   # the last: 4-column vertical kernels, one-column lateral ones
 def test_random_flow_vs_oracle(nx, ny, seed):
     """A seeded multi-step flow with every supported step kind on grids the oracle does in seconds."""
