@@ -209,25 +209,29 @@ __global__ __launch_bounds__(256) void k_wet_step(GridView s, Ghost gh, GridView
 // ------------------------------------------------------------------------------------------
 // One column's bitset in LDS: word w of the thread's column at base[w * stride].
 struct BitCol {
-    uint32_t* base; int stride; int wpc;
-    __device__ uint32_t get(int w) const { return base[(size_t)w * stride]; }
-    __device__ void set(int w, uint32_t v) const { base[(size_t)w * stride] = v; }
-    __device__ void orw(int w, uint32_t v) const { if (w >= 0 && w < wpc) base[(size_t)w * stride] |= v; }
-    __device__ void clear() const { for (int w = 0; w < wpc; w++) base[(size_t)w * stride] = 0; }
+    uint32_t* base; int stride; int wpc;                       // LDS: word offsets fit 32 bits
+    __device__ uint32_t get(int w) const { return base[w * stride]; }
+    __device__ void set(int w, uint32_t v) const { base[w * stride] = v; }
+    __device__ void orw(int w, uint32_t v) const { if ((unsigned)w < (unsigned)wpc) base[w * stride] |= v; }
+    __device__ void andn(int w, uint32_t v) const { if ((unsigned)w < (unsigned)wpc) base[w * stride] &= ~v; }
+    __device__ void clear() const { for (int w = 0; w < wpc; w++) base[w * stride] = 0; }
 };
 
 __device__ __forceinline__ uint32_t js_shl1(int n) { return 1u << (n & 31); }          // 1 << n in JavaScript
 
-// markRangeQ (cg2:170-184).  Words outside the column are dropped.
+// markRangeQ (cg2:170-184).  Words outside the column are dropped.  CLEAR: the bits markRangeQ would
+// set are cleared instead, i.e. b &= ~(what marking an empty set would give).
+template <bool CLEAR = false>
 __device__ __forceinline__ void mark_range_q(const BitCol& b, int q0, int q1) {
     if (q1 <= q0) return;
     const int w0 = (int)((unsigned)q0 >> 5), w1 = (int)((unsigned)(q1 - 1) >> 5);
     const int s0 = q0 & 31, s1 = (q1 - 1) & 31;
-    if (w0 == w1) b.orw(w0, (~(js_shl1(s0) - 1u)) & (js_shl1(s1 + 1) - 1u));
+    auto put = [&](int w, uint32_t m) { if (CLEAR) b.andn(w, m); else b.orw(w, m); };
+    if (w0 == w1) put(w0, (~(js_shl1(s0) - 1u)) & (js_shl1(s1 + 1) - 1u));
     else {
-        b.orw(w0, ~(js_shl1(s0) - 1u));
-        for (int w = w0 + 1; w < w1; w++) if (w < b.wpc) b.set(w, 0xFFFFFFFFu);
-        b.orw(w1, js_shl1(s1 + 1) - 1u);
+        put(w0, ~(js_shl1(s0) - 1u));
+        for (int w = w0 + 1; w < w1; w++) if (w < b.wpc) b.set(w, CLEAR ? 0u : 0xFFFFFFFFu);
+        put(w1, js_shl1(s1 + 1) - 1u);
     }
 }
 
@@ -235,10 +239,11 @@ __device__ __forceinline__ void mark_range_q(const BitCol& b, int q0, int q1) {
 __device__ __forceinline__ int ald_requant(const GridView& g, unsigned q) { return (int)js_round(((double)q * g.zs) * g.inv_zs); }
 
 // markRange (cg2:185-190) for the integer interval [q0, q1) of a stored layer
+template <bool CLEAR = false>
 __device__ __forceinline__ void mark_layer(const GridView& g, const BitCol& b, unsigned z0q, unsigned z1q) {
     int q0 = ald_requant(g, z0q); if (q0 < 0) q0 = 0;
     int q1 = ald_requant(g, z1q); if (q1 <= q0) q1 = q0 + 1;
-    mark_range_q(b, q0, q1);
+    mark_range_q<CLEAR>(b, q0, q1);
 }
 
 __device__ __forceinline__ int ctz32(uint32_t x) { return x ? __builtin_ctz(x) : 32; }
@@ -280,14 +285,16 @@ __device__ __forceinline__ void emit_intervals(const BitCol& b, int Zmax, F&& f)
     if (inRun) EMIT(runStartQ, Zmax);
 }
 
-// occupied bins of a column: layers of material >= 2 with positive thickness (cg2:338-364)
+// occupied bins of a column: layers of material >= 2 with positive thickness (cg2:338-364).
+// CLEAR: b &= ~occupied, without a bitset of its own for the occupied bins.
+template <bool CLEAR = false>
 __device__ __forceinline__ void mark_occupied(const GridView& g, size_t c, const BitCol& b) {
     const int l = g.len[c];
     unsigned prev = 0;
     for (int k = 0; k < l; k++) {
         const uint32_t r = g.rec[(size_t)k * g.N + c];
         const unsigned z1 = rec_z1(r);
-        if (!rec_hole(r) && rec_mat(r) >= 2 && z1 > prev) mark_layer(g, b, prev, z1);
+        if (!rec_hole(r) && rec_mat(r) >= 2 && z1 > prev) mark_layer<CLEAR>(g, b, prev, z1);
         prev = z1;
     }
 }
@@ -455,31 +462,71 @@ __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, con
     extern __shared__ uint32_t lds[];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const BitCol fill{lds + threadIdx.x, (int)blockDim.x, L.wpc};
-    const BitCol occ{lds + (size_t)L.wpc * blockDim.x + threadIdx.x, (int)blockDim.x, L.wpc};
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < s.N; c += stride) {
         const int i = (int)(c / s.ny), j = (int)(c - (size_t)i * s.ny);
-        fill.clear(); occ.clear();
+        fill.clear();
+        // Neighbouring taps give ranges that overlap, so ranges are united in registers and reach the bitset
+        // only when one starts away from the running union.  markRangeQ sets exactly the bits of [q0, q1) unless
+        // q1 is a multiple of 32 (see the top of this file); those ranges go to the bitset one by one, as they are.
+        int ua = 0, ub = 0; bool uhave = false;
+        auto add_range = [&](int q0, int q1) {
+            if ((q1 & 31) == 0) { mark_range_q(fill, q0, q1); return; }
+            if (uhave && q0 <= ub && q1 >= ua) { ua = min(ua, q0); ub = max(ub, q1); return; }
+            if (uhave) mark_range_q(fill, ua, ub);
+            ua = q0; ub = q1; uhave = true;
+        };
+        auto grow_seed = [&](const uint2 sd, const double add) {  // cg2:542-557
+            const double lo = (double)sd.x * s.zs - add, hi = (double)sd.y * s.zs + add;
+            if (hi <= lo + CG_EPS) return;
+            const double z0 = lo > 0 ? lo : 0, z1 = hi < Hcap ? hi : Hcap;
+            if (z1 <= z0 + CG_EPS) return;
+            double q0 = js_round(z0 * s.inv_zs); if (q0 < 0) q0 = 0;
+            double q1 = js_round(z1 * s.inv_zs); if (q1 <= q0) q1 = q0 + 1;
+            add_range((int)q0, (int)q1);
+        };
         if (i >= imin && i <= imax && j >= jmin && j <= jmax)
-            for (int t = 0; t < ntaps; t++) {
-                const int si = i - taps[t].du, sj = j - taps[t].dv;
-                if (si < -S.rows_lo || sj < 0 || si >= s.nx + S.rows_hi || sj >= s.ny) continue;
-                const size_t sc = S.at(s, si, sj);
-                const int ns = min((int)seed_n[sc], seed_planes);
-                const double add = taps[t].add;
-                for (int q = 0; q < ns; q++) {                 // cg2:542-557
-                    const uint2 sd = seed[(size_t)q * S.stride + sc];
-                    const double lo = (double)sd.x * s.zs - add, hi = (double)sd.y * s.zs + add;
-                    if (hi <= lo + CG_EPS) continue;
-                    const double z0 = lo > 0 ? lo : 0, z1 = hi < Hcap ? hi : Hcap;
-                    if (z1 <= z0 + CG_EPS) continue;
-                    double q0 = js_round(z0 * s.inv_zs); if (q0 < 0) q0 = 0;
-                    double q1 = js_round(z1 * s.inv_zs); if (q1 <= q0) q1 = q0 + 1;
-                    mark_range_q(fill, (int)q0, (int)q1);
+            for (int tc = 0; tc < ntaps; tc += 64) {
+                // Most columns hold one seed, a few (pattern edges) many, and every wave meets some of those:
+                // the first seed of every tap is done in step by the whole wave, four taps' loads in flight
+                // together; the taps whose column holds more are noted in `more`, and each lane then works
+                // through its own at its own pace.
+                const int tend = min(ntaps, tc + 64);
+                unsigned long long more = 0;
+                for (int t0 = tc; t0 < tend; t0 += 4) {
+                    size_t sc[4]; int ns[4]; uint2 first[4]; double add[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        ns[u] = 0; sc[u] = 0; add[u] = 0;
+                        if (t0 + u >= tend) continue;
+                        const int si = i - taps[t0 + u].du, sj = j - taps[t0 + u].dv;
+                        if (si < -S.rows_lo || sj < 0 || si >= s.nx + S.rows_hi || sj >= s.ny) continue;
+                        sc[u] = S.at(s, si, sj);
+                        ns[u] = min((int)seed_n[sc[u]], seed_planes);
+                        add[u] = taps[t0 + u].add;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) first[u] = ns[u] > 0 ? seed[sc[u]] : make_uint2(0u, 0u);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (ns[u] > 0) grow_seed(first[u], add[u]);
+                        if (ns[u] > 1) more |= 1ull << (t0 + u - tc);
+                    }
+                }
+                int q = 0, n = 0; size_t scl = 0; double addl = 0;
+                for (;;) {
+                    if (q >= n) {
+                        if (!more) break;
+                        const AldTap tp = taps[tc + __builtin_ctzll(more)];
+                        more &= more - 1;
+                        scl = S.at(s, i - tp.du, j - tp.dv); addl = tp.add;
+                        n = min((int)seed_n[scl], seed_planes); q = 1;
+                    }
+                    grow_seed(seed[(size_t)q * S.stride + scl], addl); q++;
                 }
             }
-        mark_occupied(s, c, occ);
-        for (int w = 0; w < L.wpc - 1; w++) fill.set(w, fill.get(w) & ~occ.get(w));                      // cg2:566-582
-        fill.set(L.wpc - 1, fill.get(L.wpc - 1) & ((~occ.get(L.wpc - 1)) & L.lastMask));
+        if (uhave) mark_range_q(fill, ua, ub);
+        mark_occupied<true>(s, c, fill);                       // fill & ~occ, cg2:566-582
+        fill.set(L.wpc - 1, fill.get(L.wpc - 1) & L.lastMask);
         insert_runs(s, d, c, fill, L.Zmax, mat, flags);
     }
 }

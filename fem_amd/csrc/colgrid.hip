@@ -845,7 +845,7 @@ int ald_coat(cg_grid* g, int mat, double t, const uint32_t* hmax_q = nullptr) {
     const double Hcap = Hnow + t + g->zscale;                                                    // cg2:501, 702
     const AldLayout L = make_bit_layout(g, Hcap);
     size_t lds = 0;
-    const int bt = ald_block(L, 2, &lds);
+    const int bt = ald_block(L, 1, &lds);
     if (!bt) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: %d height bins per column do not fit the bitsets", L.Zmax);
     std::vector<AldTap> taps;
     const int Rx = build_ald_taps(g, t, &taps);
