@@ -987,6 +987,13 @@ __global__ __launch_bounds__(256) void k_mask_normalise(const uint8_t* __restric
 // ------------------------------------------------------------------------------------------
 // reductions and checks
 // ------------------------------------------------------------------------------------------
+// Monotone device-wide maximum: one same-address atomic per wave serialises (a million of them cost
+// a few tenths of a millisecond), so a wave first looks at the current value and only joins in when it
+// would change it.
+__device__ __forceinline__ void lazy_umax(unsigned* p, unsigned v) {
+    if (v > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, v);
+}
+
 // out[0] = max top z1q, out[1] = max len (len must be current, see k_relen)
 __global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restrict__ out) {
     unsigned mq = 0, ml = 0;
@@ -1002,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restric
         unsigned a = __shfl_down(mq, o, 64), b = __shfl_down(ml, o, 64);
         mq = a > mq ? a : mq; ml = b > ml ? b : ml;
     }
-    if ((threadIdx.x & 63) == 0) { if (mq) atomicMax(&out[0], mq); if (ml) atomicMax(&out[1], ml); }
+    if ((threadIdx.x & 63) == 0) { lazy_umax(&out[0], mq); lazy_umax(&out[1], ml); }
 }
 
 // split form: out[0] = max top z1q from the top stream alone (an empty column's top is 0)
@@ -1015,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_max_top_split(GridView g, unsigned* __r
         mq = q > mq ? q : mq;
     }
     for (int o = 32; o > 0; o >>= 1) { unsigned a = __shfl_down(mq, o, 64); mq = a > mq ? a : mq; }
-    if ((threadIdx.x & 63) == 0 && mq) atomicMax(&out[0], mq);
+    if ((threadIdx.x & 63) == 0) lazy_umax(&out[0], mq);
 }
 
 // split form: len[c] recounted from the chain (the 4-columns-per-thread kernels do not maintain it)
@@ -1045,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_max_layers(GridView g, unsigned* __rest
         unsigned a = __shfl_down(mw, o, 64), b = __shfl_down(ml, o, 64);
         mw = a > mw ? a : mw; ml = b > ml ? b : ml;
     }
-    if ((threadIdx.x & 63) == 0) { if (mw) atomicMax(&out[0], mw); if (ml) atomicMax(&out[1], ml); }
+    if ((threadIdx.x & 63) == 0) { lazy_umax(&out[0], mw); lazy_umax(&out[1], ml); }
 }
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -1099,7 +1106,7 @@ __global__ __launch_bounds__(256) void k_cmp_stopper_top(GridView g, int stopMat
         }
     }
     for (int o = 32; o > 0; o >>= 1) { mq = max(mq, (unsigned)__shfl_down(mq, o, 64)); any |= __shfl_down(any, o, 64); }
-    if ((threadIdx.x & 63) == 0 && any) { atomicMax(&out[0], mq); atomicOr(&out[1], 1u); }
+    if ((threadIdx.x & 63) == 0 && any) { lazy_umax(&out[0], mq); lazy_umax(&out[1], 1u); }
 }
 
 // per-column truncation to limit = max(targetZ, z1 of the column's lowest stopper layer)
