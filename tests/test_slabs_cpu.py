@@ -8,7 +8,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,flow", [(2, "c4"), (3, "c4"), (2, "cs"), (3, "cs"), (2, "cwet"), (2, "cw")])
+@pytest.mark.parametrize("world,flow", [(2, "c4"), (3, "c4"), (2, "cs"), (3, "cs"), (2, "cwet"), (2, "cw"), (3, "cw")])
 def test_slab_flow_matches_whole_grid(world, flow):
     """c4: halo rows of the lateral steps.  cs: CMP, STRIP and identify_cavity across slab edges
     (all-reduced scalars and the ghost-row flood of fem_amd/slabs.py).  cwet: etch_wet increments with
