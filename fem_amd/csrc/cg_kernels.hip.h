@@ -700,6 +700,7 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
 // one add and one max serve four taps.
 // lim[du] = largest dv whose entry of row du is a float32 tap (-1: none); the ellipse is convex, so
 // the entries 0..lim[du] of a row are the valid ones and the loops stop there (uniform branches).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int R> struct AddTab { float a[(R + 1) * (R + 1)]; int lim[R + 1]; };
 
 // Tile of the symmetric kernel: TJS columns x (1024 / TJS) rows per block of 256 threads.
@@ -810,6 +811,15 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
 // no canonicalisation of loaded values (and fuses into v_max3/v_min3).
 #define CG_OP(a, b) __int_as_float(ETCH ? min(__float_as_int(a), __float_as_int(b)) : max(__float_as_int(a), __float_as_int(b)))
 #define CG_ADD(x, a) (ETCH ? ((x) - (a)) : ((x) + (a)))
+// four columns' tap at once: the two adds of a pair of columns are one packed instruction
+#define CG_TAP4(src, dv, a)                                                                                   \
+            do {                                                                                              \
+                f32x2 x01 = {CG_OP(src[Rp + 0 + (dv)], src[Rp + 0 - (dv)]), CG_OP(src[Rp + 1 + (dv)], src[Rp + 1 - (dv)])}; \
+                f32x2 x23 = {CG_OP(src[Rp + 2 + (dv)], src[Rp + 2 - (dv)]), CG_OP(src[Rp + 3 + (dv)], src[Rp + 3 - (dv)])}; \
+                const f32x2 aa = {(a), (a)};                                                                  \
+                x01 = ETCH ? x01 - aa : x01 + aa; x23 = ETCH ? x23 - aa : x23 + aa;                           \
+                m[0] = CG_OP(m[0], x01[0]); m[1] = CG_OP(m[1], x01[1]); m[2] = CG_OP(m[2], x23[0]); m[3] = CG_OP(m[3], x23[1]); \
+            } while (0)
             // centre row
 #pragma unroll
             for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(hc[Rp + c], tab.a[0]));
@@ -817,8 +827,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
             for (int dv = 1; dv <= R; dv++) {
                 if (dv > tab.lim[0]) break;
                 const float a = tab.a[dv];
-#pragma unroll
-                for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(CG_OP(hc[Rp + c + dv], hc[Rp + c - dv]), a));
+                CG_TAP4(hc, dv, a);
             }
             // row pairs +-du: v[k] = op(row+du[k], row-du[k]) is shared by every dv
 #pragma unroll
@@ -838,8 +847,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                 for (int dv = 1; dv <= R; dv++) {
                     if (dv > tab.lim[du]) break;
                     const float a = tab.a[du * (R + 1) + dv];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], CG_ADD(CG_OP(v[Rp + c + dv], v[Rp + c - dv]), a));
+                    CG_TAP4(v, dv, a);
                 }
             }
             // taps whose increment is too fine for float32: double, like the reference
@@ -860,6 +868,7 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
 #pragma unroll
                 for (int c = 0; c < 4; c++) m[c] = (float)md[c];
             }
+#undef CG_TAP4
 #undef CG_OP
 #undef CG_ADD
             // ---- per-column update
