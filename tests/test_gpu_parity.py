@@ -730,15 +730,18 @@ def test_slab_driver_on_one_gpu(parts, flow_name):
     """fem_amd.slabs.SlabGrid itself (halo rows, all-reduced scalars, ghost-row flood of STRIP /
     identify_cavity, CMP) with P slabs driven by P threads on one device: the summed checksum equals
     the undivided grid's and the oracle's after every step."""
+    from fem_amd import flows
+    nxl = 40
+    _run_slab_flow(parts, flows.FLOWS[flow_name](), flows.mask_specs(2.0 * nxl * parts), nxl, 72)
+
+
+def _run_slab_flow(parts, flow, specs, nxl, ny):
     import threading
     import torch
     fem = _engine()
     from fem_amd import flows
     from fem_amd.slabs import SlabGrid
-    nxl, ny = 40, 72
     nxg = nxl * parts
-    flow = flows.FLOWS[flow_name]()
-    specs = flows.mask_specs(2.0 * nxg)
     o = OracleGrid(2.0 * nxg, 2.0 * ny, 2.0, 2.0)
     names = sorted({s["mask"] for s in flow if s["mask"]})
     reds = {n: fem.reduce_mask(flows.shapes_of(specs[n], 2 * nxg, 2 * ny)) for n in names}
@@ -772,3 +775,34 @@ def test_slab_driver_on_one_gpu(parts, flow_name):
     for t in threads:
         t.join(timeout=100)
     assert not errors, errors[0]
+
+
+def test_slab_ald_when_one_slab_holds_far_more_seeds():
+    """deposit_ALD over two slabs of which only the upper one is patterned: its columns hold many seeds, the
+    flat slab's one each, so the flat slab has to widen its seed arrays before the boundary rows' seeds arrive;
+    the coat (3 rows of reach) crosses the slab edge in both directions."""
+    from fem_amd import flows
+    nxl, ny = 24, 40
+    L = 2.0 * nxl * 2
+    specs = {"Mup": {"kind": "shapes", "data": {"objects": [
+        {"type": "rect", "left": 0, "top": 0, "width": 4 * L, "height": 4 * L, "angle": 0, "scaleX": 1, "scaleY": 1,
+         "visible": True, "data": {"polarity": "positive"}},
+        {"type": "rect", "left": L / 2 + 0.5, "top": 10, "width": 14, "height": 30, "angle": 0, "scaleX": 1, "scaleY": 1,
+         "visible": True, "data": {"polarity": "negative"}},
+        {"type": "circle", "left": L / 2 + 20, "top": 44, "radius": 9, "width": 18, "height": 18, "angle": 0, "scaleX": 1, "scaleY": 1,
+         "visible": True, "data": {"polarity": "negative"}}]}}}
+    s = flows._s
+    flow = [s("SUBSTR", None, 3, 20), s("DEPO", None, 4, 6), s("DEPO", None, 5, 5), s("DEPO", None, 4, 4), s("DEPO", None, 6, 5),
+            s("ETCH", "Mup", 255, 17), s("WETETCH", None, 4, 3), s("ALD", None, 7, 5.5), s("ALD", None, 5, 2)]
+    _run_slab_flow(2, flow, specs, nxl, ny)
+
+
+def test_slab_ald_refuses_a_slab_thinner_than_the_coat_reach():
+    fem = _engine()
+    g = fem.ColumnGrid(dx=2.0, dy=2.0, slab=(8, 16, 2, 2))
+    g.deposit_general(None, 3, 10, 0)
+    import torch
+    ghost = torch.zeros(g.ghost_bytes(4), dtype=torch.uint8, device="cuda")
+    with pytest.raises(Exception, match="reaches"):
+        g.ald_collect_seeds_slab(7.0, 100, 4, ghost.data_ptr(), ghost.data_ptr())
+    g.close()
