@@ -1,0 +1,27 @@
+"""Wider seeded sweeps of the GPU-vs-oracle parity tests (not collected by pytest; run on a GPU box as
+`python tests/stress_gpu.py`): the random-flow tests of test_gpu_parity.py with 48 more seeds and sizes."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import test_gpu_parity as t          # noqa: E402
+
+for seed in range(5, 25):
+    nx, ny = 96 + 4 * ((seed * 37) % 60), 64 + 4 * ((seed * 53) % 70)
+    if seed % 5 == 0:
+        nx += 1                      # the one-column kernels
+    t.test_random_flow_vs_oracle(nx, ny, seed)
+    print("general seed", seed, nx, ny, "ok", flush=True)
+for n in (50, 400, 1200):
+    for slab in (None, (70, 150)):
+        t.test_mask_rasteriser_many_shapes(n, slab)
+for seed in range(30, 46):
+    nx, ny = 64 + 4 * ((seed * 29) % 30), 60 + 4 * ((seed * 41) % 30)
+    t.test_random_flow_with_wet_etch_and_ald_vs_oracle(nx, ny, seed)
+    print("wet/ald seed", seed, nx, ny, "ok", flush=True)
+for seed in range(50, 62):
+    nx, ny = 80 + 4 * ((seed * 29) % 50), 72 + 4 * ((seed * 41) % 50)
+    t.test_random_flow_with_strip_cmp_cavity_vs_oracle(nx, ny, seed)
+    print("strip/cmp seed", seed, nx, ny, "ok", flush=True)
+print("stress ok")
