@@ -11,7 +11,9 @@ Layer stacks never move between GPUs.  Whole-domain scalars (max height, checksu
 target height, "is there any gap") are all-reduced.  strip_connected / identify_cavity flood
 across slab edges: each rank relaxes to its local fixpoint, swaps one boundary row (whole
 columns with their flood marks) with each neighbour, and the ranks stop when a round changed
-nothing anywhere.  The reference is single-threaded (template/script_columngrid.js); this file has
+nothing anywhere.  etch_wet swaps the same ghost row before every increment (a cut reaches one
+column sideways); deposit_ALD swaps it once, then the seeds of the rows a coat can reach, once.
+The reference is single-threaded (template/script_columngrid.js); this file has
 no counterpart there.
 
 `grid` is any object with stencil_begin / stencil_finish / halo access in the style of
