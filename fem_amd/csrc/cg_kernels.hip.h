@@ -1288,24 +1288,25 @@ __global__ __launch_bounds__(256) void k_strip_compact(GridView g, int* __restri
     int gap = 0, cav = 0;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
-        int w = 0;
-        bool dirty = false;
+        int w = 0, nh = 0, nc = 0;                 // intervals kept, gaps and cavity layers among them
+        bool dirty = false, below_hole = false;    // below_hole: the interval at w - 1 is a gap
         for (int k = 0; k < l; k++) {
             uint32_t r = g.rec[(size_t)k * g.N + c];
             if (r & REC_MARK) { r = rec_z1(r) | REC_HOLE; dirty = true; }
-            if (rec_hole(r) && w > 0 && rec_hole(g.rec[(size_t)(w - 1) * g.N + c])) { w--; dirty = true; }   // merge with the gap below
+            const bool hole = rec_hole(r);
+            if (hole && below_hole) { w--; nh--; dirty = true; }              // merge with the gap below
             if (dirty || w != k) g.rec[(size_t)w * g.N + c] = r;
+            if (hole) nh++; else if (rec_mat(r) == 2) nc++;
+            below_hole = hole;
             w++;
         }
-        while (w > 0 && rec_hole(g.rec[(size_t)(w - 1) * g.N + c])) { w--; dirty = true; }                    // no gap on top
+        if (below_hole) { w--; nh--; dirty = true; }                          // no gap on top (gaps never neighbour each other here)
         if (dirty) {
             for (int k = w; k < l; k++) g.rec[(size_t)k * g.N + c] = 0;
             g.len[c] = (uint8_t)w;
         }
-        for (int k = 0; k < w; k++) {
-            const uint32_t r = g.rec[(size_t)k * g.N + c];
-            if (rec_hole(r)) gap = 1; else if (rec_mat(r) == 2) cav = 1;
-        }
+        if (nh > 0) gap = 1;
+        if (nc > 0) cav = 1;
     }
     if (gap) flags[2] = 1;
     if (cav) flags[1] = 1;
