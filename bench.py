@@ -143,7 +143,7 @@ def main():
         grid.set_stream(stream.cuda_stream)
         names = sorted({s["mask"] for s in flow if s["mask"]})
         masks = build_masks(fem_amd, flows, grid, specs, names, nxl, ny, rank * nxl, LX, LY, device)
-        slab = SlabGrid(grid, rank, world, device=device, dx=2.0, dy=2.0, ny=ny)
+        slab = SlabGrid(grid, rank, world, device=device, dx=2.0, dy=2.0, ny=ny, stream=stream)
 
         # C5 also extracts cross-sections after every step: 64 YZ lines at i = 512 s + 256 and 64 XZ lines
         # at the same j, into device buffers in the reference layout (one launch per axis)

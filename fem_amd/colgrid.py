@@ -60,10 +60,12 @@ ABI = {
     "cg_get_info": (_i, [_vp, C.POINTER(CgInfo)]),
     "cg_last_error": (C.c_char_p, [_vp]),
     "cg_set_stream": (_i, [_vp, _vp]),
+    "cg_get_stream": (_i, [_vp, _pp]),
     "cg_sync": (_i, [_vp]),
     "cg_mask_from_raster": (_i, [_vp, _vp, _sz, C.POINTER(_i)]),
     "cg_mask_from_device_raster": (_i, [_vp, _vp, _sz, C.POINTER(_i)]),
     "cg_mask_from_shapes": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(_i)]),
+    "cg_mask_any_open": (_i, [_vp, _i, C.POINTER(_i)]),
     "cg_mask_download": (_i, [_vp, _i, _vp, _sz]),
     "cg_mask_destroy": (_i, [_vp, _i]),
     "cg_deposit_general": (_i, [_vp, _i, _i, _d, _d]),
@@ -304,6 +306,12 @@ class ColumnGrid:
     def set_stream(self, stream_ptr):
         self._chk(self.lib.cg_set_stream(self.h, stream_ptr))
 
+    def get_stream(self):
+        """The hipStream_t (as an int) the handle's work is enqueued on."""
+        p = C.c_void_p()
+        self._chk(self.lib.cg_get_stream(self.h, C.byref(p)))
+        return p.value or 0
+
     # ---- masks
     def mask_from_raster(self, raster):
         r = np.ascontiguousarray(raster, dtype=np.uint8).reshape(-1)
@@ -323,6 +331,12 @@ class ColumnGrid:
         self._chk(self.lib.cg_mask_from_shapes(self.h, C.cast(arr, C.c_void_p), n,
                                                pts.ctypes.data if pts.size else None, pts.size // 2, C.byref(mid)))
         return Mask(self, mid.value)
+
+    def mask_any_open(self, mask):
+        """Does the mask open any column of this handle (None: yes)?"""
+        a = C.c_int()
+        self._chk(self.lib.cg_mask_any_open(self.h, self._mid(mask), C.byref(a)))
+        return bool(a.value)
 
     def mask_from_data(self, mask_data):
         red = reduce_mask(mask_data)

@@ -988,6 +988,16 @@ __global__ __launch_bounds__(256) void k_mask_shapes_binned(int nx, int ny, int 
     }
 }
 
+// out[0] = 1 if any byte of the raster is non-zero (n bytes; 4 at a time, then the tail)
+__global__ __launch_bounds__(256) void k_mask_any(const uint8_t* __restrict__ m, size_t n, unsigned* __restrict__ out) {
+    const size_t n4 = n >> 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned any = 0;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) any |= ((const unsigned*)m)[q];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) any |= m[4 * n4 + threadIdx.x];
+    if (any) out[0] = 1;
+}
+
 __global__ __launch_bounds__(256) void k_mask_normalise(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += stride) out[c] = in[c] ? 1 : 0;

@@ -100,6 +100,7 @@ struct cg_grid {
     bool pristine = false;                                // every column is empty, but len / top / link still hold old bytes (see zero_planes)
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<uint8_t*> masks;
+    std::vector<int8_t> mask_any;                         // per mask: does it open any column of this handle (-1: not looked at yet)
     std::deque<ConfKernel*> kcache;
     // halo messages of a lateral step on a slab
     uint8_t* halo[4] = {nullptr, nullptr, nullptr, nullptr}; size_t halo_cap = 0;  // send lo/up, recv lo/up
@@ -113,7 +114,7 @@ struct cg_grid {
     int* d_flags = nullptr; unsigned* d_red = nullptr; unsigned long long* d_sum = nullptr;
     unsigned long long* d_stats = nullptr; bool stats_on = false; uint64_t stats_host[CG_NSTAT] = {0};
     // slice staging
-    uint8_t* sl_mat = nullptr; uint16_t* sl_zp = nullptr; uint8_t* sl_len = nullptr; size_t sl_cap = 0;
+    uint8_t* sl_mat = nullptr; uint16_t* sl_zp = nullptr; uint8_t* sl_len = nullptr; size_t sl_cap = 0, sl_cols_cap = 0;   // slots / columns allocated
     int32_t* sl_idx = nullptr; int sl_idx_cap = 0; std::vector<int32_t> sl_idx_host; int sl_idx_axis = -1;   // the request last uploaded
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // per-kernel timing (cg_profile): event pairs recorded around launches, resolved on read
@@ -918,7 +919,7 @@ int cg_create_slab(int nx_global, int ny, int i0, int nx_local, double dx, doubl
         HIPCHK(g, hipStreamCreateWithFlags(&g->own_stream, hipStreamNonBlocking));
         g->stream = g->own_stream;
         HIPCHK(g, hipMalloc(&g->d_flags, 4 * sizeof(int)));
-        HIPCHK(g, hipMalloc(&g->d_red, 4 * sizeof(unsigned)));
+        HIPCHK(g, hipMalloc(&g->d_red, 8 * sizeof(unsigned)));
         HIPCHK(g, hipMalloc(&g->d_sum, sizeof(unsigned long long)));
         HIPCHK(g, hipMalloc(&g->d_bbox, 4 * sizeof(int)));
         HIPCHK(g, hipMalloc(&g->d_stats, CG_NSTAT * sizeof(unsigned long long)));
@@ -1011,14 +1012,48 @@ int cg_set_stream(cg_grid* g, void* s) {
     return CG_OK;
 }
 
+int cg_get_stream(cg_grid* g, void** s) {
+    NEED_H(g);
+    if (!s) return fail(g, CG_ERR_ARG, "null output");
+    *s = (void*)g->stream;
+    return CG_OK;
+}
+
 int cg_sync(cg_grid* g) { NEED_H(g); HIPCHK(g, hipStreamSynchronize(g->stream)); return CG_OK; }
 
 // ---- masks ----------------------------------------------------------------------------------
 static int new_mask_slot(cg_grid* g, uint8_t** buf, int* id) {
     HIPCHK(g, hipMalloc(buf, std::max<size_t>(g->N, 1)));
     for (size_t k = 0; k < g->masks.size(); k++)
-        if (!g->masks[k]) { g->masks[k] = *buf; *id = (int)k; return CG_OK; }
-    g->masks.push_back(*buf); *id = (int)g->masks.size() - 1;
+        if (!g->masks[k]) { g->masks[k] = *buf; g->mask_any[k] = -1; *id = (int)k; return CG_OK; }
+    g->masks.push_back(*buf); g->mask_any.push_back(-1); *id = (int)g->masks.size() - 1;
+    return CG_OK;
+}
+
+// Does the mask open any column of this handle?  Looked up once per mask (rasters never change).
+static int mask_opens_any(cg_grid* g, int mask_id, bool* any) {
+    *any = true;
+    if (mask_id == CG_MASK_NONE) return CG_OK;
+    if (mask_id < 0 || (size_t)mask_id >= g->masks.size() || !g->masks[mask_id]) return fail(g, CG_ERR_ARG, "unknown mask id %d", mask_id);
+    if (g->mask_any[mask_id] < 0) {
+        unsigned r = 0;
+        HIPCHK(g, hipMemsetAsync(g->d_red + 4, 0, sizeof(unsigned), g->stream));
+        hipLaunchKernelGGL(k_mask_any, dim3(blocks_for(g->N / 4 + 1)), dim3(256), 0, g->stream, g->masks[mask_id], g->N, g->d_red + 4);
+        HIPCHK(g, hipGetLastError());
+        HIPCHK(g, hipMemcpyAsync(&r, g->d_red + 4, sizeof r, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        g->mask_any[mask_id] = r ? 1 : 0;
+    }
+    *any = g->mask_any[mask_id] != 0;
+    return CG_OK;
+}
+
+int cg_mask_any_open(cg_grid* g, int mask_id, int* any) {
+    NEED_H(g);
+    if (!any) return fail(g, CG_ERR_ARG, "null output");
+    bool a = true;
+    int rc = mask_opens_any(g, mask_id, &a); if (rc) return rc;
+    *any = a ? 1 : 0;
     return CG_OK;
 }
 
@@ -1188,10 +1223,10 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     bool ok; const uint8_t* mask = mask_ptr(g, mask_id, &ok);
     if (!ok) return fail(g, CG_ERR_ARG, "unknown mask id %d", mask_id);
     if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
-    if (std::isnan(thickness) || std::isnan(conformality)) return fail(g, CG_ERR_ARG, "NaN thickness or conformality");
-    const double t = std::max(0.0, thickness);
+    // a thickness / conformality that is not a number reaches the grid as 0 (Number(x) || 0, rt:154-156)
+    const double t = std::isnan(thickness) ? 0.0 : std::max(0.0, thickness);
     if (!(t > 0)) return CG_OK;                                           // cg1:437, 600
-    const double S = std::max(0.0, std::min(1.0, conformality));          // cg1:440, 603
+    const double S = std::isnan(conformality) ? 0.0 : std::max(0.0, std::min(1.0, conformality));   // cg1:440, 603
     const double latRange = t * S;
     // a reset grid whose first step is a deposit everywhere needs no clearing pass: the kernel writes
     // top and link of every column itself
@@ -1221,6 +1256,14 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
                                             "script_columngrid.js:471, 666)");
     ConfKernel* K = get_kernel(g, t, S);
     const int R = K->Rx;
+    // A lateral deposit whose mask opens no column returns before anything changes, identify_cavity
+    // included (cg1:474-485; the kernel cache above has its entry by then, cg1:470).  On a slab the
+    // question is about the whole domain: the driver asks cg_mask_any_open on every slab.
+    if (kind == CG_STENCIL_DEPOSIT && mask && g->nx == g->nx_global) {
+        bool any = true;
+        int rca = mask_opens_any(g, mask_id, &any); if (rca) return rca;
+        if (!any) return CG_OK;
+    }
     if (stencil_lds_bytes(R) > 160 * 1024) return fail(g, CG_ERR_UNSUPPORTED, "stencil radius %d cells does not fit the LDS tile", R);
     if ((has_lower || has_upper) && g->nx < R)
         return fail(g, CG_ERR_UNSUPPORTED, "slab of %d rows is thinner than the stencil radius %d", g->nx, R);
@@ -2019,13 +2062,17 @@ int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count, void
         const int lim = axis == 0 ? g->nx : g->ny;
         if (index[s] < 0 || index[s] >= lim) return fail(g, CG_ERR_ARG, "slice index %d outside [0,%d)", index[s], lim);
     }
-    if (need * L > g->sl_cap) {
+    // two capacities: slots (columns x L) for mat / zpair, columns for len -- L can shrink (reset, snapshot
+    // of a lower Lmax, upload) while the number of columns grows
+    if (need * L > g->sl_cap || need > g->sl_cols_cap) {
+        HIPCHK(g, hipStreamSynchronize(g->stream));
         if (g->sl_mat) (void)hipFree(g->sl_mat);
         if (g->sl_zp) (void)hipFree(g->sl_zp);
         if (g->sl_len) (void)hipFree(g->sl_len);
-        g->sl_mat = nullptr; g->sl_zp = nullptr; g->sl_len = nullptr; g->sl_cap = 0;
-        HIPCHK(g, hipMalloc(&g->sl_mat, need * L)); HIPCHK(g, hipMalloc(&g->sl_zp, need * L * 4)); HIPCHK(g, hipMalloc(&g->sl_len, need));
-        g->sl_cap = need * L;
+        const size_t slots = std::max(need * L, g->sl_cap), cols = std::max(need, g->sl_cols_cap);
+        g->sl_mat = nullptr; g->sl_zp = nullptr; g->sl_len = nullptr; g->sl_cap = 0; g->sl_cols_cap = 0;
+        HIPCHK(g, hipMalloc(&g->sl_mat, slots)); HIPCHK(g, hipMalloc(&g->sl_zp, slots * 4)); HIPCHK(g, hipMalloc(&g->sl_len, cols));
+        g->sl_cap = slots; g->sl_cols_cap = cols;
     }
     if (count > g->sl_idx_cap) {
         if (g->sl_idx) (void)hipFree(g->sl_idx);

@@ -19,6 +19,7 @@ no counterpart there.
 `grid` is any object with stencil_begin / stencil_finish / halo access in the style of
 fem_amd.ColumnGrid; the tests drive the same class with a CPU stand-in over the gloo backend.
 """
+import contextlib
 import math
 
 import torch
@@ -73,7 +74,15 @@ class TorchComm:
 
 
 class SlabGrid:
-    def __init__(self, grid, rank=0, world=1, device=None, group=None, dx=2.0, dy=2.0, ny=None, halo_rows=32, comm=None):
+    """stream: the torch.cuda.Stream everything of this slab is ordered on when the communicator moves
+    device buffers itself (RCCL).  The handle's kernels and the communication calls must share ONE
+    stream: RCCL orders its transfers against torch's current stream only, and a handle's own stream
+    is a non-blocking one that nothing else waits for.  Given None, the driver makes a stream of its
+    own; either way it points the handle at it (grid.set_stream) and issues every communication call
+    with it current."""
+
+    def __init__(self, grid, rank=0, world=1, device=None, group=None, dx=2.0, dy=2.0, ny=None, halo_rows=32, comm=None,
+                 stream=None):
         self.grid, self.rank, self.world, self.group = grid, rank, world, group
         self.device = device if device is not None else torch.device("cpu")
         self.comm = comm if comm is not None else (TorchComm(rank, world, self.device, group) if world > 1 else None)
@@ -83,13 +92,38 @@ class SlabGrid:
         self._halo = None
         self._rows = 0
         self._gaps_anywhere = None      # "some slab may hold a gap or a cavity": None = ask the ranks again
+        self._mask_any = {}             # mask id -> "open somewhere in the domain" (all-reduced once per mask)
+        self.stream = None
+        if self.device_side_comm():
+            self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
+            self.grid.set_stream(self.stream.cuda_stream)
         if world > 1:
             self._alloc_halo(halo_rows)
+
+    def device_side_comm(self):
+        """True when the communicator hands device buffers to the transport as they are (RCCL), i.e. when
+        ordering between the handle's kernels and the transfers is a matter of streams."""
+        return (self.comm is not None and not getattr(self.comm, "stage", False)
+                and torch.device(self.device).type == "cuda")
+
+    def _on_stream(self):
+        """Context in which communication calls and torch allocations are issued: the slab's stream current."""
+        if isinstance(self.stream, torch.cuda.Stream):
+            return torch.cuda.stream(self.stream)
+        return contextlib.nullcontext()
+
+    def _zeros(self, nbytes, count=4):
+        """Device (or host) byte buffers, cleared and ready for the handle's stream."""
+        with self._on_stream():
+            bufs = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(count)]
+        if self.stream is None and torch.device(self.device).type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()      # the handle's own stream does not wait for torch's
+        return bufs
 
     # ---- halo buffers live in torch so that torch.distributed can move them
     def _alloc_halo(self, rows):
         nbytes = rows * self.ny * 3
-        self._halo = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(4)]
+        self._halo = self._zeros(nbytes)
         self._rows = rows
         self.grid.set_halo_buffers(*[t.data_ptr() for t in self._halo], nbytes)
 
@@ -105,13 +139,14 @@ class SlabGrid:
         n = R * self.ny * 3
         bufs = [t[:n] for t in self._halo]
         interior = getattr(self.grid, "stencil_interior", None)
-        if interior is None or not hasattr(self.comm, "start_swap"):
-            return self.comm.swap(*bufs)
-        if getattr(self.comm, "stage", False):
-            self.grid.sync()                     # the rows are copied to the host by torch, not on the grid's stream
-        reqs = self.comm.start_swap(*bufs)
-        interior()
-        self.comm.finish_swap(reqs)
+        if not self.device_side_comm():
+            self.grid.sync()                     # the rows are read by the host / by torch, not on the grid's stream
+        with self._on_stream():
+            if interior is None or not hasattr(self.comm, "start_swap"):
+                return self.comm.swap(*bufs)
+            reqs = self.comm.start_swap(*bufs)
+            interior()
+            self.comm.finish_swap(reqs)
 
     def _step(self, kind, mask, mat, t, S):
         if self.world > 1:
@@ -126,18 +161,32 @@ class SlabGrid:
         self.grid.stencil_finish()
 
     def _reduce_max(self, values):
-        return [int(v) for v in self.comm.reduce([int(v) for v in values], "max")]
+        with self._on_stream():
+            return [int(v) for v in self.comm.reduce([int(v) for v in values], "max")]
 
     def _swap_ghosts(self, nbytes):
         """My row 0 becomes the lower neighbour's upper ghost, my last row the upper neighbour's lower ghost."""
-        self.comm.swap(*[t[:nbytes] for t in self._ghost])
+        with self._on_stream():
+            self.comm.swap(*[t[:nbytes] for t in self._ghost])
+
+    def _open_somewhere(self, mask):
+        """Does the mask open a cell anywhere in the domain?  (One all-reduce per mask; rasters never change.)"""
+        if mask is None or not hasattr(self.grid, "mask_any_open"):
+            return True
+        key = getattr(mask, "id", id(mask))
+        if key not in self._mask_any:
+            self._mask_any[key] = bool(self._reduce_max([1 if self.grid.mask_any_open(mask) else 0])[0])
+        return self._mask_any[key]
 
     # ---- the reference's step names
     def deposit_general(self, mask, matId, thickness, conformality=1.0):
+        lateral = self._radius(thickness, conformality) > 0
+        if self.world > 1 and lateral and not self._open_somewhere(mask):
+            return                                       # no open cell in the whole domain: script_columngrid.js:485
         if matId == 2:
             self._gaps_anywhere = None                   # material 2 is what identify_cavity strips
         self._step(STENCIL_DEPOSIT, mask, matId, thickness, conformality)
-        if self.world > 1 and self._radius(thickness, conformality) > 0:
+        if self.world > 1 and lateral:
             self.identify_cavity()                       # script_columngrid.js:543; a slab handle leaves it to us
 
     def invalidate(self):
@@ -166,7 +215,7 @@ class SlabGrid:
         """(bytes per message, send lower, send upper, received lower or 0, received upper or 0)."""
         nbytes = self.grid.ghost_bytes(planes)
         if getattr(self, "_ghost", None) is None or self._ghost[0].numel() < nbytes:
-            self._ghost = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(4)]
+            self._ghost = self._zeros(nbytes)
         s_lo, s_up, r_lo, r_up = [t.data_ptr() for t in self._ghost]
         return nbytes, s_lo, s_up, (r_lo if self.has_lower else 0), (r_up if self.has_upper else 0)
 
@@ -205,7 +254,7 @@ class SlabGrid:
 
     def _seed_buffers(self, nbytes):
         if getattr(self, "_seedbuf", None) is None or self._seedbuf[0].numel() < nbytes:
-            self._seedbuf = [torch.zeros(max(nbytes, 8), dtype=torch.uint8, device=self.device) for _ in range(4)]
+            self._seedbuf = self._zeros(max(nbytes, 8))
         s_lo, s_up, r_lo, r_up = [t.data_ptr() for t in self._seedbuf]
         return s_lo, s_up, (r_lo if self.has_lower else 0), (r_up if self.has_upper else 0)
 
@@ -230,7 +279,8 @@ class SlabGrid:
         nbytes = g.ald_seed_halo_bytes(seed_planes)
         s_lo, s_up, lo, up = self._seed_buffers(nbytes)
         g.ald_seed_halo_pack(seed_planes, s_lo, s_up); g.sync()
-        self.comm.swap(*[t[:nbytes] for t in self._seedbuf])
+        with self._on_stream():
+            self.comm.swap(*[t[:nbytes] for t in self._seedbuf])
         g.ald_seed_halo_unpack(seed_planes, lo, up); g.sync()
         try:
             t = step
@@ -292,13 +342,15 @@ class SlabGrid:
     def maxHeight(self):
         z = self.grid.maxHeight()
         if self.world > 1:
-            z = float(self.comm.reduce([z], "max", torch.float64)[0])
+            with self._on_stream():
+                z = float(self.comm.reduce([z], "max", torch.float64)[0])
         return z
 
     def checksum(self):
         """Sum of the per-slab checksums mod 2^64 = checksum of the undivided grid."""
         s = self.grid.checksum()
         if self.world > 1:
-            lo, hi = [int(v) for v in self.comm.reduce([s & 0xFFFFFFFF, s >> 32], "sum")]
+            with self._on_stream():
+                lo, hi = [int(v) for v in self.comm.reduce([s & 0xFFFFFFFF, s >> 32], "sum")]
             s = (lo + (hi << 32)) & 0xFFFFFFFFFFFFFFFF
         return s

@@ -123,6 +123,8 @@ const char* cg_last_error(const cg_grid* g);
 /* Use the caller's HIP stream (hipStream_t passed as void*) for all work of this handle;
  * NULL switches back to the handle's own stream. */
 int cg_set_stream(cg_grid* g, void* hip_stream);
+/* The stream the handle's work is enqueued on right now (hipStream_t as void*). */
+int cg_get_stream(cg_grid* g, void** hip_stream);
 int cg_sync(cg_grid* g);
 
 /* ---- masks (rt:45-141) --------------------------------------------------------------- */
@@ -144,6 +146,11 @@ int cg_mask_from_device_raster(cg_grid* g, const void* dev_raster, size_t n, int
  * (x0,y0,x1,y1,...), npts = number of doubles / 2. */
 int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes,
                         const double* pts, int npts, int* mask_id);
+
+/* Does the mask open any column of THIS handle (CG_MASK_NONE: yes)?  deposit_general's lateral path
+ * returns untouched -- no identify_cavity either -- when no cell of the domain is open (cg1:474-485);
+ * an undivided grid checks that itself, a slab driver asks every slab and combines the answers. */
+int cg_mask_any_open(cg_grid* g, int mask_id, int* any);
 
 int cg_mask_download(cg_grid* g, int mask_id, uint8_t* host_out, size_t n);
 int cg_mask_destroy(cg_grid* g, int mask_id);

@@ -214,6 +214,22 @@ const etc = (mask, mat, t, S = 0, dump = false) => ({ op: 'etch_general', mask, 
   ]);
 }
 
+// 7a. a lateral deposit whose mask opens no cell returns before identify_cavity (cg1:474-485): a cavity that an
+//     etch has opened to the air stays until the next cavity pass; vertical deposits and etches with the same mask
+{
+  const masks = {
+    trench: { objects: [rect(0, 0, 200, 200), rect(24, 10, 14, 50, neg)] },
+    pit: { objects: [rect(0, 0, 200, 200), rect(30, 20, 6, 6, neg)] },
+    closed: { objects: [rect(-10, -10, 400, 400)] },
+  };
+  runCase('empty_mask_small', D(96, 72), masks, [
+    dep('all', 3, 20, 0), dep('all', 4, 8, 0), dep('all', 5, 12, 0), etc('trench', 255, 25, 0),
+    { op: 'strip_connected', mat: 4 }, dep('all', 6, 6, 1.0, true), etc('pit', 255, 14, 0, true),
+    dep('closed', 7, 6, 1.0, true), dep('closed', 7, 6, 0, true), etc('closed', 255, 5, 1.0, true),
+    dep(null, 7, 3, 1.0, true),
+  ]);
+}
+
 // 7b. wet etch and ALD (cg2:111 - cg3:308): undercut, pinch-off cavities, the slider caches,
 //     and thin gaps that put several runs of air into one 32-bin word of the ALD bitsets
 {

@@ -34,6 +34,8 @@ for name in ("c4", "cs", "cwet", "cw"):
     om = {n: o.mask_raster(reds[n]) for n in names}
     gm = {n: g.mask_from_shapes(reds[n]) for n in names}
     slab = SlabGrid(g, rank, world, device=dev, ny=ny, halo_rows=4)
+    if slab.device_side_comm():      # RCCL: the handle's kernels and the transfers share one stream
+        assert slab.stream is not None and g.get_stream() == slab.stream.cuda_stream
     for k, st in enumerate(flow):
         flows.apply_step(slab, st, gm)
         flows.apply_step(o, st, om)

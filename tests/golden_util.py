@@ -8,7 +8,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 STEP_CASES = ["vertical_small", "stencil_small", "stencil_odd", "anchor_256", "masks_small",
-              "growth_small", "cavity_small", "kcache_small", "wet_ald_small", "wet_ald_cache", "wet_ald_thin", "accessors_small"]
+              "growth_small", "cavity_small", "empty_mask_small", "kcache_small", "wet_ald_small", "wet_ald_cache", "wet_ald_thin", "accessors_small"]
 
 
 def load_case(name):

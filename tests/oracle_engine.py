@@ -33,6 +33,9 @@ class OracleSlabEngine:
     def createNewGrid(self):
         self.o.reset()
 
+    def mask_any_open(self, mask):
+        return True if mask is None else bool(np.asarray(mask).any())
+
     def _tops_q(self):
         ln, mat, zp = self.o.arrays()
         L = self.o.Lmax
