@@ -115,6 +115,7 @@ ABI = {
     "cg_snapshot_drop": (_i, [_vp, _i]),
     "cg_slices": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "cg_slices_device": (_i, [_vp, _i, _vp, _i, _pp, _pp, _pp]),
+    "cg_slices_noalloc": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "cg_index_from_pos": (_i, [_vp, _i, _d, C.POINTER(C.c_int32)]),
     "cg_checksum": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "cg_step_stats": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
@@ -661,6 +662,12 @@ class ColumnGrid:
         ax = {"YZ": 0, "XZ": 1}[axis] if isinstance(axis, str) else int(axis)
         idx = np.ascontiguousarray(indices, dtype=np.int32)
         self._chk(self.lib.cg_slices_device(self.h, ax, idx.ctypes.data, idx.size, None, None, None))
+
+    def slices_noalloc(self, axis, indices, d_mat, d_zpair, d_len):
+        """Cross-sections into the caller's device buffers (pointers as ints) without any allocation: see cg_slices_noalloc."""
+        ax = {"YZ": 0, "XZ": 1}[axis] if isinstance(axis, str) else int(axis)
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        self._chk(self.lib.cg_slices_noalloc(self.h, ax, idx.ctypes.data, idx.size, d_mat, d_zpair, d_len))
 
     def index_from_pos(self, axis, pos):
         out = C.c_int32()

@@ -2096,6 +2096,52 @@ int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count, void
     return CG_OK;
 }
 
+// ---- cross-sections without any allocation --------------------------------------------------------
+// The index list of cg_slices_noalloc is staged in this array instead of a buffer the library
+// allocates.  Every GPU holds its own copy at its own address until the process ends; all handles on
+// one GPU share that copy.  In host code the name `scratch` is only a stand-in for the symbol: the
+// device address is looked up once per device (scratch_on_device) and that pointer is what copies
+// and kernels get.
+static __device__ __align__(256) int32_t scratch[CG_SLICES_NOALLOC_MAX];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+int32_t* g_scratch_ptr[MAX_DEVICES] = {nullptr};
+
+// device address of `scratch` on the handle's device (which the caller has made current)
+int scratch_on_device(cg_grid* g, int32_t** out) {
+    if (g->device < 0 || g->device >= MAX_DEVICES) return fail(g, CG_ERR_UNSUPPORTED, "device ordinal %d beyond %d", g->device, MAX_DEVICES);
+    if (!g_scratch_ptr[g->device]) {
+        int32_t* p = nullptr;
+        HIPCHK(g, hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(g, CG_ERR_HIP, "hipGetSymbolAddress gave a null address");
+        g_scratch_ptr[g->device] = p;
+    }
+    *out = g_scratch_ptr[g->device];
+    return CG_OK;
+}
+}  // namespace
+
+int cg_slices_noalloc(cg_grid* g, int axis, const int32_t* index, int count, void* d_mat, void* d_zpair, void* d_len) {
+    NEED(g);
+    if ((axis != 0 && axis != 1) || !index || count < 1 || !d_mat || !d_zpair || !d_len) return fail(g, CG_ERR_ARG, "bad slice request");
+    if (count > CG_SLICES_NOALLOC_MAX)
+        return fail(g, CG_ERR_ARG, "cg_slices_noalloc takes at most %d lines per call, %d asked (split the request or use cg_slices_device)",
+                    CG_SLICES_NOALLOC_MAX, count);
+    const size_t line = axis == 0 ? (size_t)g->ny : (size_t)g->nx;
+    const int lim = axis == 0 ? g->nx : g->ny;
+    for (int s = 0; s < count; s++)
+        if (index[s] < 0 || index[s] >= lim) return fail(g, CG_ERR_ARG, "slice index %d outside [0,%d)", index[s], lim);
+    int32_t* d_idx = nullptr;
+    { int rc = scratch_on_device(g, &d_idx); if (rc) return rc; }
+    // only the first `count` entries are rewritten; the kernel reads no others
+    HIPCHK(g, hipMemcpyAsync(d_idx, index, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
+    hipLaunchKernelGGL(k_gather_slices, dim3(blocks_for(line * count)), dim3(256), 0, g->stream, view(g), axis, d_idx, count, line, g->lmax_vis,
+                       (g->split && !g->len_valid) ? 1 : 0, (uint8_t*)d_mat, (uint16_t*)d_zpair, (uint8_t*)d_len);
+    HIPCHK(g, hipGetLastError());
+    return CG_OK;
+}
+
 int cg_slices(cg_grid* g, int axis, const int32_t* index, int count, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
     if (!mat || !zpair || !len) return fail(g, CG_ERR_ARG, "null output array");
     int rc = cg_slices_device(g, axis, index, count, nullptr, nullptr, nullptr); if (rc) return rc;

@@ -339,6 +339,19 @@ int cg_slices(cg_grid* g, int axis, const int32_t* index, int count,
 int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count,
                      void** d_mat, void** d_zpair, void** d_len);
 
+/* The same cross-sections for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
+ * reference.  The caller owns the outputs, all in DEVICE memory: d_mat count*line_cols*lmax bytes,
+ * d_zpair 4 times that, d_len count*line_cols bytes (line_cols = ny for axis 0, nx for axis 1;
+ * lmax = cg_info.lmax).  index is a host array.  The call allocates and frees nothing: the index list
+ * is staged in a fixed array of CG_SLICES_NOALLOC_MAX entries (16 KiB) that lives in the library's
+ * device image, one copy per GPU, shared by every handle on that GPU.  count beyond the maximum is
+ * refused with CG_ERR_ARG.  Work is enqueued on the handle's stream and not waited for; two calls that
+ * overlap in time on one GPU (two handles on different streams, two threads) race on the shared array. */
+#define CG_SLICES_NOALLOC_MAX 4096
+int cg_slices_noalloc(cg_grid* g, int axis, const int32_t* index, int count,
+                      void* d_mat, void* d_zpair, void* d_len);
+
 /* indexFromX / indexFromY (sl:15-16): clamp(round((pos - offset)/pitch), 0, n-1). */
 int cg_index_from_pos(const cg_grid* g, int axis, double pos_nm, int32_t* index);
 
