@@ -1,6 +1,6 @@
 // Device code of libcolgrid: the per-column process kernels for gfx950 (MI355X).
 //
-// A column is a stack of contiguous intervals z1q | mat << 16 | flags << 24 (u32); interval k
+// A column is a stack of contiguous intervals z1q | mat << 16 | flags << 24 (u32, see REC_*); interval k
 // spans from the top of interval k-1 (0 for k = 0) to its own z1, so the bottom height is never
 // stored in a record.  That is exactly what the reference's columns look like as long as they
 // have no vertical gaps (every append starts at the old top, script_columngrid.js:419-423).  A
@@ -14,20 +14,23 @@
 //                what the kernels that restructure whole columns work on (strip, cavity, CMP,
 //                wet etch, ALD, upload).
 //
-//   split form   top[c] u32 = the top interval (0: empty column), link[c] u8 = the plane holding
-//                the interval below it (whose z1 is the top's bottom; LINK_NONE if there is none),
-//                and for an interval stored in plane p: rec[p*N + c], prv[p*N + c] u8 = the plane of
-//                the one below (LINK_NONE for the bottom interval).  len[c] is NOT kept up to date
-//                by the 4-columns-per-thread kernels -- the chain says everything they need -- and
-//                is recounted from the chain (k_relen) before anything reads it.
+//   split form   top[c] u32 = the top interval (0: empty column); the six high bits of every
+//                record name the plane that holds the interval below it (whose z1 is this one's
+//                bottom; LNK_NONE if there is none), so a column is the chain top[c] ->
+//                rec[lnk*N + c] -> ...  and an append moves 12 bytes: the old top is read, stored
+//                as it is into the plane P of the launch, and the new top (link = P) is stored.
+//                len[c] is NOT kept up to date by the 4-columns-per-thread kernels -- the chain says
+//                everything they need -- and is recounted from the chain (k_relen) before anything
+//                reads it.
 //                What the vertical and lateral steps work on: they only ever look at the top, so
-//                extend / partial etch / "material differs" touch streams whose addresses do not
-//                depend on the column length.  An append pushes the old top into the plane P of
-//                the launch -- every depositing launch takes a fresh plane, so that these writes
-//                fill whole 128-byte lines whatever the lengths of neighbouring columns (measured:
-//                4-byte pieces scattered over planes cost up to 3x, the memory side
-//                read-modify-writes partial lines) -- and the removal of a whole layer follows
-//                link / prv.  Plane slots outside a column's chain hold unspecified data.
+//                extend / partial etch / "material differs" touch one stream whose addresses do not
+//                depend on the column length.  Every depositing launch takes a fresh plane, so that
+//                its pushes fill whole 128-byte lines whatever the lengths of neighbouring columns
+//                (measured: 4-byte pieces scattered over planes cost up to 3x, the memory side
+//                read-modify-writes partial lines), and the removal of a whole layer follows the
+//                links.  Six bits: planes 0..62, i.e. columns of up to 64 intervals; beyond that the
+//                host keeps the grid in whole form.  Plane slots outside a column's chain hold
+//                unspecified data.
 //
 // A thread owns 4 consecutive columns: HBM is only reached with >= 4 bytes per lane and access
 // (measured on MI355X: 1 B/lane copies at 1.8 TB/s, 2 B/lane 3.0, 4 B/lane 5.4, 16 B/lane 5.7).
@@ -49,8 +52,6 @@ struct GridView {
     uint32_t* rec;
     uint32_t* top;      // split form: the top interval of every column (0 for an empty column)
     uint32_t* top_w;    // where updated tops are stored: top itself, or the other buffer in a lateral step
-    uint8_t*  link;     // split form: plane that holds the interval below the top, LINK_NONE if len < 2
-    uint8_t*  prv;      // split form: prv[p*N + c] = plane of the interval below the one stored in plane p, or LINK_NONE
     int       P;        // split form: the plane this launch pushes old tops into (-1: it cannot append)
     int       split;    // 1: split form (see below); 0: whole form, planes hold intervals 0..len-1 by index
     size_t    N;        // columns of this handle
@@ -64,16 +65,21 @@ struct GridView {
     double    inv_zs;   // 1/zs, rounded once on the host
 };
 
-constexpr int LINK_NONE = 255;              // link / prv: no interval below (so at most 255 planes are ever linked)
 constexpr uint32_t REC_HOLE = 1u << 24;     // a vertical gap, not a layer
-constexpr uint32_t REC_MARK = 2u << 24;     // scratch bit of the flood fill (strip_connected)
-constexpr uint32_t REC_RUN  = 4u << 24;     // the nearest layer below has the same material
-constexpr uint32_t REC_LAYER = 8u << 24;    // set in every layer record: a record is 0 only where there is none
+constexpr uint32_t REC_LAYER = 2u << 24;    // set in every layer record: a record is 0 only where there is none
+constexpr uint32_t REC_MARK = 4u << 24;     // whole form only: scratch bit of the flood fill (strip_connected)
+constexpr int LNK_SHIFT = 26;               // split form only: bits 26..31 = plane of the interval below
+constexpr int LNK_NONE = 63;                // no interval below (so planes 0..62 can be linked)
+constexpr uint32_t REC_BODY = (1u << LNK_SHIFT) - 1u;      // everything but the link
+// whole form: a layer record (bits 26..31 clear)
 __device__ __forceinline__ uint32_t rec_make(uint32_t z1q, int mat) { return (z1q & 0xffffu) | ((uint32_t)(mat & 255) << 16) | REC_LAYER; }
+// split form: a layer record above the interval stored in plane lnk
+__device__ __forceinline__ uint32_t rec_make_l(uint32_t z1q, int mat, int lnk) { return rec_make(z1q, mat) | ((uint32_t)lnk << LNK_SHIFT); }
+__device__ __forceinline__ int rec_lnk(uint32_t r) { return (int)(r >> LNK_SHIFT); }
 __device__ __forceinline__ uint32_t rec_z1(uint32_t r) { return r & 0xffffu; }
 __device__ __forceinline__ int rec_mat(uint32_t r) { return (int)((r >> 16) & 255u); }
 __device__ __forceinline__ bool rec_hole(uint32_t r) { return (r & REC_HOLE) != 0; }
-__device__ __forceinline__ uint32_t rec_with_z1(uint32_t r, uint32_t z1q) { return (r & 0xffff0000u) | (z1q & 0xffffu); }
+__device__ __forceinline__ uint32_t rec_with_z1(uint32_t r, uint32_t z1q) { return (r & 0xffff0000u) | (z1q & 0xffffu); }    // link and flags stay
 
 // statistics slots (cg_step_stats)
 enum { ST_VISITED = 0, ST_OPEN = 1, ST_EXTEND = 2, ST_APPEND = 3, ST_ETCHED = 4, ST_REMOVED = 5, ST_FLOOR = 6, ST_N = 8 };
@@ -118,28 +124,35 @@ __device__ __forceinline__ uint16_t quantz(double z, double zs, double inv_zs) {
 __device__ __forceinline__ void load_column(const GridView& g, size_t c, int l, uint32_t* out) {
     if (!g.split) { for (int k = 0; k < l; k++) out[k] = g.rec[(size_t)k * g.N + c]; return; }
     if (l <= 0) return;
-    out[l - 1] = g.top[c];
-    int p = g.link[c];
+    uint32_t r = g.top[c];
+    out[l - 1] = r & REC_BODY;                                 // links are not part of what a reader sees
     for (int k = l - 2; k >= 0; k--) {
-        out[k] = g.rec[(size_t)p * g.N + c];
-        if (k > 0) p = g.prv[(size_t)p * g.N + c];
+        r = g.rec[(size_t)rec_lnk(r) * g.N + c];
+        out[k] = r & REC_BODY;
     }
 }
 
+// split form: intervals in the chain of column c
+__device__ __forceinline__ int chain_length(const GridView& g, size_t c) {
+    uint32_t r = g.top[c];
+    if (r == 0) return 0;
+    int l = 1;
+    for (int p = rec_lnk(r); p != LNK_NONE && l < 255; p = rec_lnk(r)) { r = g.rec[(size_t)p * g.N + c]; l++; }
+    return l;
+}
+
 // The column has just lost its top; l intervals remain (l >= 1) and lk is the plane of the
-// topmost of them.  Loads the new top, drops it too if it is a gap (a gap is never on top), and
-// looks up the new bottom and the new link.
-__device__ __forceinline__ void reload_top(const GridView& g, size_t c, int& l, uint32_t& r, unsigned& z0q, int& lk) {
-    r = g.rec[(size_t)lk * g.N + c];
-    int p2 = g.prv[(size_t)lk * g.N + c];
+// topmost of them.  Loads the new top (its link comes with it), drops it too if it is a gap (a gap
+// is never on top), and looks up the new bottom.
+__device__ __forceinline__ void reload_top(const GridView& g, size_t c, int& l, uint32_t& r, unsigned& z0q) {
+    r = g.rec[(size_t)rec_lnk(r) * g.N + c];
     if (rec_hole(r)) {
         l -= 1;
-        if (l == 0) { r = 0; z0q = 0; lk = LINK_NONE; return; }
-        r = g.rec[(size_t)p2 * g.N + c];
-        p2 = g.prv[(size_t)p2 * g.N + c];
+        if (l == 0 || rec_lnk(r) == LNK_NONE) { l = 0; r = 0; z0q = 0; return; }
+        r = g.rec[(size_t)rec_lnk(r) * g.N + c];
     }
-    z0q = p2 != LINK_NONE ? rec_z1(g.rec[(size_t)p2 * g.N + c]) : 0u;
-    lk = p2;
+    const int p2 = rec_lnk(r);
+    z0q = p2 != LNK_NONE ? rec_z1(g.rec[(size_t)p2 * g.N + c]) : 0u;
 }
 
 // _depoAtTop_ (script_columngrid.js:397-426) for one column.  `l` is the column's current
@@ -152,12 +165,8 @@ __device__ __forceinline__ int depo_at_top(const GridView& g, size_t c, int l, i
     const uint16_t q = quantz((double)topq * g.zs + dz, g.zs, g.inv_zs);
     if (l > 0 && rec_mat(r) == matId) { g.top_w[c] = rec_with_z1(r, q); return 1; }
     if (l >= g.lmax) return 3;
-    if (l > 0) {                                               // the old top goes into this step's plane
-        g.rec[(size_t)g.P * g.N + c] = r;
-        g.prv[(size_t)g.P * g.N + c] = g.link[c];
-        g.link[c] = (uint8_t)g.P;
-    }
-    g.top_w[c] = rec_make(q, matId);                           // another material below: RUN stays clear
+    if (l > 0) g.rec[(size_t)g.P * g.N + c] = r;               // the old top goes into this step's plane, link and all
+    g.top_w[c] = rec_make_l(q, matId, l > 0 ? g.P : LNK_NONE);
     g.len[c] = (uint8_t)(l + 1);
     return 2;
 }
@@ -184,42 +193,39 @@ __device__ __forceinline__ int apply_etch_at(const GridView& g, size_t c, int l,
     int removed = 0; bool touched = false;
     const int l0 = l;
     uint32_t r = g.top[c];
-    int lk = g.link[c];
-    unsigned z0q = lk != LINK_NONE ? rec_z1(g.rec[(size_t)lk * g.N + c]) : 0u;
+    unsigned z0q = rec_lnk(r) != LNK_NONE ? rec_z1(g.rec[(size_t)rec_lnk(r) * g.N + c]) : 0u;
     while (etch_round(g, r, z0q, l, remaining, matId, isAll, touched, removed)) {
-        if (l > 0) reload_top(g, c, l, r, z0q, lk); else { r = 0; z0q = 0; lk = LINK_NONE; }
+        if (l > 0 && rec_lnk(r) != LNK_NONE) reload_top(g, c, l, r, z0q); else { l = 0; r = 0; z0q = 0; }
     }
     if (touched) {
         g.top_w[c] = r;
-        if (l != l0) { g.len[c] = (uint8_t)l; g.link[c] = (uint8_t)lk; }
+        if (l != l0) g.len[c] = (uint8_t)l;
     }
     return (touched ? 0x10000 : 0) | removed;
 }
 
-// bottom of the top run of matId (script_columngrid.js:646-660); the top layer (record r, bottom
-// z0q, link lk) is known to be matId.  Gaps do not interrupt the run (the reference only compares
-// materials).  The RUN flag of a record says that the nearest layer below it has the same
-// material, so the usual case -- the run is the top layer alone -- needs no look at the stack.
-__device__ __forceinline__ double floor_of_top_run(const GridView& g, size_t c, int lk, int matId, uint32_t r, unsigned z0q, unsigned& scanned) {
+// bottom of the top run of matId (script_columngrid.js:646-660); the top layer (record r) is known
+// to be matId and b is the interval below it (valid when r has a link).  Gaps do not interrupt the
+// run (the reference only compares materials).  The usual case -- the layer below is another
+// material -- is decided by b, which the caller needs anyway for the cut.
+__device__ __forceinline__ double floor_of_top_run(const GridView& g, size_t c, int matId, uint32_t r, uint32_t b, unsigned& scanned) {
     scanned++;
-    if (!(r & REC_RUN)) return (double)z0q * g.zs;
-    int p = lk;                    // plane of the topmost interval not known to belong to the run
-    while (p != LINK_NONE) {
-        const uint32_t b = g.rec[(size_t)p * g.N + c];
-        if (rec_hole(b)) {         // look through the gap at the layer under it
-            const int p2 = g.prv[(size_t)p * g.N + c];
-            if (p2 == LINK_NONE) break;
-            const uint32_t b2 = g.rec[(size_t)p2 * g.N + c];
-            if (rec_mat(b2) != matId) break;
-            scanned++;
-            p = g.prv[(size_t)p2 * g.N + c];
-            continue;
+    int p = rec_lnk(r);            // plane of the topmost interval not known to belong to the run
+    if (p == LNK_NONE) return 0.0;
+    uint32_t cur = b;              // the interval in plane p
+    for (;;) {
+        uint32_t lay = cur;        // the layer to compare with: cur, or what lies under the gap cur
+        if (rec_hole(cur)) {
+            if (rec_lnk(cur) == LNK_NONE) break;
+            lay = g.rec[(size_t)rec_lnk(cur) * g.N + c];
         }
-        if (rec_mat(b) != matId) break;
+        if (rec_mat(lay) != matId) break;
         scanned++;
-        p = g.prv[(size_t)p * g.N + c];
+        p = rec_lnk(lay);
+        if (p == LNK_NONE) return 0.0;
+        cur = g.rec[(size_t)p * g.N + c];
     }
-    return p != LINK_NONE ? (double)rec_z1(g.rec[(size_t)p * g.N + c]) * g.zs : 0.0;
+    return (double)rec_z1(cur) * g.zs;
 }
 
 // block-wide accumulation of statistics into global counters
@@ -274,11 +280,11 @@ __global__ __launch_bounds__(256) void k_vertical_1(GridView g, const uint8_t* _
 // ------------------------------------------------------------------------------------------
 // 4 columns per thread ("groups")
 // ------------------------------------------------------------------------------------------
-// A thread owns 4 consecutive columns: len and mask move as one dword, the 4 top records as one
-// 16-byte vector, their bottoms as one 8-byte vector -- four streams whose addresses do not
-// depend on the column lengths.  Only an append (old top -> its plane) and the removal of a
-// whole layer (new top <- its plane) touch the planes; columns of a group that do so at the
-// same length share one 16-byte access.  N % 4 == 0.
+// A thread owns 4 consecutive columns: the mask moves as one dword, the 4 top records as one
+// 16-byte vector -- streams whose addresses do not depend on the column lengths.  Only an append
+// (old top -> the launch's plane), a cut (the top's bottom <- the plane its link names) and the
+// removal of a whole layer (new top <- that plane) touch the planes; columns of a group whose
+// links name the same plane share one 16-byte access.  N % 4 == 0.
 typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -293,12 +299,12 @@ __device__ __forceinline__ u16x4 ld_u16x4(const uint16_t* p) { return *(const u1
 __device__ __forceinline__ void st_u16x4(uint16_t* p, u16x4 v) { *(u16x4*)p = v; }
 __device__ __forceinline__ unsigned open_bits(u8x4 mk) { return (mk[0] ? 1u : 0u) | (mk[1] ? 2u : 0u) | (mk[2] ? 4u : 0u) | (mk[3] ? 8u : 0u); }
 
-// _depoAtTop_ on the open columns of a group: column j grows by dz[j] (> 0).  tv = the 4 tops,
-// lk = their links.  Returns whether the group's tops were stored.  The host launches this form
-// only while every column has a plane to spare (the reference's growth rule needs the lengths).
+// _depoAtTop_ on the open columns of a group: column j grows by dz[j] (> 0).  tv = the 4 tops.
+// Returns whether the group's tops were stored.  The host launches this form only while every
+// column has a plane to spare (the reference's growth rule needs the lengths).
 template <bool STATS>
 __device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsigned open, const double (&dz)[4], int matId,
-                                            u32x4 tv, u8x4 lk, unsigned& n_ext, unsigned& n_app) {
+                                            u32x4 tv, unsigned& n_ext, unsigned& n_app) {
     u32x4 nv = tv;
     unsigned ext = 0, app = 0, push = 0;
 #pragma unroll
@@ -307,26 +313,18 @@ __device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsign
         const uint32_t r = tv[j];                              // 0: empty column
         const uint32_t q = quantz((double)rec_z1(r) * g.zs + dz[j], g.zs, g.inv_zs);
         if (r != 0 && rec_mat(r) == matId) { nv[j] = rec_with_z1(r, q); ext |= 1u << j; }
-        else { nv[j] = rec_make(q, matId); app |= 1u << j; if (r != 0) push |= 1u << j; }
+        else { nv[j] = rec_make_l(q, matId, r != 0 ? g.P : LNK_NONE); app |= 1u << j; if (r != 0) push |= 1u << j; }
     }
     if (!(ext | app)) return false;
     if (push) {
-        // the old tops go into this step's plane (whatever the column lengths: one dense line per
-        // 32 columns), each with the link to what was below it
+        // the old tops go into this step's plane as they are -- each carries the link to what is
+        // below it -- whatever the column lengths: one dense line per 32 columns
         const size_t b = (size_t)g.P * g.N + c0;
-        u8x4 nk = lk;
-        if (push == 15u) {
-            st_rec4(g.rec + b, tv);
-            st_u8x4(g.prv + b, lk);
-            nk = splat4(g.P);
-        } else {
+        if (push == 15u) st_rec4(g.rec + b, tv);
+        else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (!((push >> j) & 1)) continue;
-                g.rec[b + j] = tv[j]; g.prv[b + j] = lk[j]; nk[j] = (uint8_t)g.P;
-            }
+            for (int j = 0; j < 4; j++) if ((push >> j) & 1) g.rec[b + j] = tv[j];
         }
-        st_u8x4(g.link + c0, nk);
     }
     if (STATS) n_app += __popc(app);
     st_rec4(g.top_w + c0, nv);
@@ -334,83 +332,73 @@ __device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsign
     return true;
 }
 
-// The intervals below the tops of the columns in `want` (those whose link is not LINK_NONE): their
-// records b[] -- the top's bottom is rec_z1(b), and b is the new top should the whole top layer
-// go -- and their links pv[] (loaded along with the records: fetching them only once a layer is
-// known to go costs a round trip more per removed layer, measured 10 % on such steps).  Columns
-// whose links name the same plane (they were pushed by the same step) share the vector loads.
-__device__ __forceinline__ void load_below4(const GridView& g, size_t c0, unsigned want, const int (&lk)[4], uint32_t (&b)[4], int (&pv)[4]) {
+// The intervals below the tops r[] of the columns in `want` (those that have one): their records
+// b[] -- the top's bottom is rec_z1(b), and b, link included, is the new top should the whole top
+// layer go.  Columns whose links name the same plane (they were pushed by the same step) share
+// one vector load.
+__device__ __forceinline__ void load_below4(const GridView& g, size_t c0, unsigned want, const uint32_t (&r)[4], uint32_t (&b)[4]) {
     unsigned todo = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) if (((want >> j) & 1) && lk[j] != LINK_NONE) todo |= 1u << j;
+    for (int j = 0; j < 4; j++) if (((want >> j) & 1) && rec_lnk(r[j]) != LNK_NONE) todo |= 1u << j;
     while (todo) {
         const int j0 = __ffs(todo) - 1;
-        const int p = lk[j0];
+        const int p = rec_lnk(r[j0]);
         unsigned sel = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) if (((todo >> j) & 1) && lk[j] == p) sel |= 1u << j;
+        for (int j = 0; j < 4; j++) if (((todo >> j) & 1) && rec_lnk(r[j]) == p) sel |= 1u << j;
         todo &= ~sel;
         const size_t at = (size_t)p * g.N + c0;
         if (sel & (sel - 1)) {
             const u32x4 A = ld_rec4(g.rec + at);
-            const u8x4 PV = ld_u8x4(g.prv + at);
 #pragma unroll
-            for (int j = 0; j < 4; j++) if ((sel >> j) & 1) { b[j] = A[j]; pv[j] = PV[j]; }
+            for (int j = 0; j < 4; j++) if ((sel >> j) & 1) b[j] = A[j];
         } else {
-            b[j0] = g.rec[at + j0]; pv[j0] = g.prv[at + j0];
+            b[j0] = g.rec[at + j0];
         }
     }
 }
 
 // _applyEtchAt on the open columns of a group: column j loses dz[j] (> 0) from the top.
-// tv / lkv = the 4 tops and their links; `have` names the columns whose interval below the top
-// the caller has loaded already (b0 / pv0, see load_below4).  A column that loses its whole top
-// layer continues with the interval below it.
+// tv = the 4 tops; `have` names the columns whose interval below the top the caller has loaded
+// already (b0, see load_below4).  A column that loses its whole top layer continues with the
+// interval below it.
 template <bool STATS>
 __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsigned open, const double (&dz)[4], int matId,
-                                            bool isAll, u32x4 tv, u8x4 lkv, unsigned have, const uint32_t (&b0)[4], const int (&pv0)[4],
+                                            bool isAll, u32x4 tv, unsigned have, const uint32_t (&b0)[4],
                                             unsigned& n_touched, unsigned& n_removed) {
-    int lk[4] = {lkv[0], lkv[1], lkv[2], lkv[3]};
     uint32_t r[4] = {tv[0], tv[1], tv[2], tv[3]};
     double rem[4] = {dz[0], dz[1], dz[2], dz[3]};
     uint32_t b[4] = {b0[0], b0[1], b0[2], b0[3]};
-    int pv[4] = {pv0[0], pv0[1], pv0[2], pv0[3]};
-    unsigned dirty = 0, popped = 0, act = 0;
+    unsigned dirty = 0, act = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if (((open >> j) & 1) && r[j] != 0 && rem[j] > CG_EPS && (isAll || rec_mat(r[j]) == matId)) act |= 1u << j;   // cg1:565-569
     while (act) {
-        load_below4(g, c0, act & ~have, lk, b, pv);
+        load_below4(g, c0, act & ~have, r, b);
         have = 0;
         unsigned next = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (!((act >> j) & 1)) continue;
-            const bool has_below = lk[j] != LINK_NONE;
+            const bool has_below = rec_lnk(r[j]) != LNK_NONE;
             const uint32_t below = has_below ? b[j] : 0u;
             const double z1 = (double)rec_z1(r[j]) * g.zs, z0 = (double)rec_z1(below) * g.zs, thick = z1 - z0;
             dirty |= 1u << j;
             if (rem[j] < thick - CG_EPS) { r[j] = rec_with_z1(r[j], quantz(z1 - rem[j], g.zs, g.inv_zs)); rem[j] = 0; continue; }   // cg1:574-578
-            rem[j] -= thick; popped |= 1u << j;                                                                                     // cg1:579-587
+            rem[j] -= thick;                                                                                                        // cg1:579-587
             if (STATS) n_removed += 1;
-            if (!has_below) { r[j] = 0; continue; }
-            r[j] = below; lk[j] = pv[j];
+            r[j] = below;                                      // 0 when nothing was below: the column is empty now
             if (rec_hole(r[j])) {                              // a gap under the removed layer goes with it
-                if (lk[j] == LINK_NONE) { r[j] = 0; continue; }
-                const size_t at = (size_t)lk[j] * g.N + c0 + j;
-                r[j] = g.rec[at]; lk[j] = g.prv[at];
+                if (rec_lnk(r[j]) == LNK_NONE) { r[j] = 0; continue; }
+                r[j] = g.rec[(size_t)rec_lnk(r[j]) * g.N + c0 + j];
             }
-            if (rem[j] > CG_EPS && (isAll || rec_mat(r[j]) == matId)) next |= 1u << j;
+            if (r[j] != 0 && rem[j] > CG_EPS && (isAll || rec_mat(r[j]) == matId)) next |= 1u << j;
         }
         act = next;
     }
     if (dirty) {
         u32x4 nv; nv[0] = r[0]; nv[1] = r[1]; nv[2] = r[2]; nv[3] = r[3];
         st_rec4(g.top_w + c0, nv);
-        if (popped) {
-            u8x4 nk; nk[0] = (uint8_t)lk[0]; nk[1] = (uint8_t)lk[1]; nk[2] = (uint8_t)lk[2]; nk[3] = (uint8_t)lk[3];
-            st_u8x4(g.link + c0, nk);
-        }
     }
     if (STATS) n_touched += __popc(dirty);
     return dirty != 0;
@@ -418,8 +406,8 @@ __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsign
 
 // Vertical deposit / etch (fast paths, cg1:445-454 and 609-618).  A thread owns U groups that
 // are 256 groups apart; all their loads are issued before anything is computed or stored.
-// fresh (deposit without a mask only): every column is empty and top / link have not been cleared
-// since the grid was reset -- nothing is loaded, and the launch leaves both streams defined.
+// fresh (deposit without a mask only): every column is empty and the tops have not been cleared
+// since the grid was reset -- nothing is loaded, and the launch leaves the stream defined.
 template <bool ETCH, bool STATS, int U>
 __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* __restrict__ mask, int matId, double t, int fresh,
                                                      int* __restrict__ flags, unsigned long long* gstats) {
@@ -440,19 +428,15 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
         if (tile >= ntiles) continue;
         if (row_tiles > 1) { const size_t r = tile / row_tiles, q = tile - r * row_tiles; tile = r * row_tiles + (q + r) % row_tiles; }
         const size_t gbase = tile * tile_groups + threadIdx.x;
-        u8x4 lk[U]; unsigned open[U]; u32x4 tv[U];
+        unsigned open[U]; u32x4 tv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const size_t gi = gbase + (size_t)u * 256;
-            open[u] = 0; lk[u] = splat4(0); tv[u] = (u32x4)(0);
+            open[u] = 0; tv[u] = (u32x4)(0);
             if (gi < ngroups) {
                 const size_t c0 = gi << 2;
                 open[u] = mask ? open_bits(ld_u8x4(mask + c0)) : 15u;
-                if (!ETCH && fresh) lk[u] = splat4(LINK_NONE);
-                else if (open[u]) {
-                    lk[u] = ld_u8x4(g.link + c0);
-                    tv[u] = ld_rec4(g.top + c0);
-                }
+                if (open[u] && !(!ETCH && fresh)) tv[u] = ld_rec4(g.top + c0);
             }
         }
 #pragma unroll
@@ -460,12 +444,9 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
             if (!open[u]) continue;
             const size_t c0 = (gbase + (size_t)u * 256) << 2;
             if (STATS) loc[0] += __popc(open[u]);
-            if (ETCH) { const uint32_t nb[4] = {0, 0, 0, 0}; const int np[4] = {0, 0, 0, 0};
-                        etch_group4<STATS>(g, c0, open[u], dz, matId, isAll, tv[u], lk[u], 0u, nb, np, loc[1], loc[2]); }
-            else {
-                depo_group4<STATS>(g, c0, open[u], dz, matId, tv[u], lk[u], loc[1], loc[2]);
-                if (fresh) st_u8x4(g.link + c0, splat4(LINK_NONE));
-            }
+            if (ETCH) { const uint32_t nb[4] = {0, 0, 0, 0};
+                        etch_group4<STATS>(g, c0, open[u], dz, matId, isAll, tv[u], 0u, nb, loc[1], loc[2]); }
+            else depo_group4<STATS>(g, c0, open[u], dz, matId, tv[u], loc[1], loc[2]);
         }
     }
     if (STATS) {
@@ -658,9 +639,9 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 if (ETCH) {
                     float F = 0.f;
                     if (!isAll && l > 0) {
-                        const int lk = g.link[c];
-                        const unsigned z0q = lk != LINK_NONE ? rec_z1(g.rec[(size_t)lk * g.N + c]) : 0u;
-                        F = (float)fmax(0.0, floor_of_top_run(g, c, lk, matId, g.top[c], z0q, loc[3]));
+                        const uint32_t rt = g.top[c];
+                        const uint32_t below = rec_lnk(rt) != LNK_NONE ? g.rec[(size_t)rec_lnk(rt) * g.N + c] : 0u;
+                        F = (float)fmax(0.0, floor_of_top_run(g, c, matId, rt, below, loc[3]));
                     }
                     float hp = fmaxf(0.f, fmaxf(F, m[r]));             // cg1:725
                     double dz = (double)own[r] - (double)hp;
@@ -872,7 +853,6 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
 #undef CG_OP
 #undef CG_ADD
             // ---- per-column update
-            const u8x4 lkv = ld_u8x4(g.link + c0);
             double dz[4] = {0, 0, 0, 0};
             unsigned open = 0;
             if (STATS) loc[0] += __popc(act);
@@ -883,24 +863,24 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
                     const double d = (double)m[c] - (double)own[c];          // cg1:534-537
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) stored = depo_group4<STATS>(g, c0, open, dz, matId, tv, lkv, loc[1], loc[2]);
+                if (open) stored = depo_group4<STATS>(g, c0, open, dz, matId, tv, loc[1], loc[2]);
             } else {
                 // every etchable column needs the bottom of its top layer: for the floor (when a
                 // material is named) and for the cut itself
-                const int k4[4] = {lkv[0], lkv[1], lkv[2], lkv[3]};
-                uint32_t b4[4] = {0, 0, 0, 0}; int p4[4] = {0, 0, 0, 0};
-                load_below4(g, c0, act, k4, b4, p4);
+                const uint32_t r4[4] = {tv[0], tv[1], tv[2], tv[3]};
+                uint32_t b4[4] = {0, 0, 0, 0};
+                load_below4(g, c0, act, r4, b4);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     if (!((act >> c) & 1)) continue;
                     // floor = bottom of the top run of matId (cg1:646-660)
                     float F = 0.f;
-                    if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, k4[c], matId, tv[c], k4[c] != LINK_NONE ? rec_z1(b4[c]) : 0u, loc[3]));
+                    if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, matId, tv[c], b4[c], loc[3]));
                     const float hpv = fmaxf(0.f, fmaxf(F, m[c]));                     // cg1:725
                     const double d = (double)own[c] - (double)hpv;
                     if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
-                if (open) stored = etch_group4<STATS>(g, c0, open, dz, matId, isAll, tv, lkv, act, b4, p4, loc[1], loc[2]);
+                if (open) stored = etch_group4<STATS>(g, c0, open, dz, matId, isAll, tv, act, b4, loc[1], loc[2]);
             }
         }
         if (!stored && g.top_w != g.top) st_rec4(g.top_w + c0, tv);       // columns that stay as they are
@@ -1048,12 +1028,7 @@ __global__ __launch_bounds__(256) void k_max_top_split(GridView g, unsigned* __r
 __global__ __launch_bounds__(256) void k_relen(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
-        int l = 0;
-        if (g.top[c] != 0) {
-            l = 1;
-            for (int p = g.link[c]; p != LINK_NONE && l < 255; p = g.prv[(size_t)p * g.N + c]) l++;
-        }
-        g.len[c] = (uint8_t)l;
+        g.len[c] = (uint8_t)chain_length(g, c);
     }
 }
 
@@ -1415,9 +1390,7 @@ __global__ __launch_bounds__(256) void k_gather_columns(GridView g, size_t col0,
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < ncols; s += stride) {
         const size_t c = col0 + s * col_stride;
-        int l = 0;
-        if (!count_chain) l = g.len[c];
-        else if (g.top[c] != 0) { l = 1; for (int p = g.link[c]; p != LINK_NONE && l < 255; p = g.prv[(size_t)p * g.N + c]) l++; }
+        const int l = count_chain ? chain_length(g, c) : (int)g.len[c];
         uint32_t col[256];
         load_column(g, c, l, col);
         olen[s] = (uint8_t)store_reference_row(col, l, L, omat + s * (size_t)L, ozp + 2 * s * (size_t)L);
@@ -1434,9 +1407,7 @@ __global__ __launch_bounds__(256) void k_gather_slices(GridView g, int axis, con
     for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
         const size_t q = s / line, p = s - q * line;
         const size_t c = axis == 0 ? (size_t)index[q] * g.ny + p : p * g.ny + (size_t)index[q];
-        int l = 0;
-        if (!count_chain) l = g.len[c];
-        else if (g.top[c] != 0) { l = 1; for (int pl = g.link[c]; pl != LINK_NONE && l < 255; pl = g.prv[(size_t)pl * g.N + c]) l++; }
+        const int l = count_chain ? chain_length(g, c) : (int)g.len[c];
         uint32_t col[256];
         load_column(g, c, l, col);
         olen[s] = (uint8_t)store_reference_row(col, l, L, omat + s * (size_t)L, ozp + 2 * s * (size_t)L);
@@ -1475,7 +1446,7 @@ __global__ __launch_bounds__(256) void k_scatter_columns(GridView g, size_t col0
 // ------------------------------------------------------------------------------------------
 // the two forms of a column
 // ------------------------------------------------------------------------------------------
-// split -> whole: the chain top -> link -> prv -> ... is laid out by index in the planes.  A
+// split -> whole: the chain that starts at the top is laid out by index in the planes, links cleared.  A
 // column's planes are its own, so it is read completely before anything of it is written.
 __global__ __launch_bounds__(256) void k_demote(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1488,24 +1459,20 @@ __global__ __launch_bounds__(256) void k_demote(GridView g) {
     }
 }
 
-// whole -> split: top / link from the planes (interval k stays in plane k, chained to
-// plane k-1), and the RUN flag of every interval brought up to date (the kernels that
-// restructure columns do not maintain it)
+// whole -> split: interval k stays in plane k and gets the link to plane k-1; the top interval is
+// copied to the top stream.  The host has checked that no column is taller than LNK_NONE + 1.
 __global__ __launch_bounds__(256) void k_promote(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
-        int below_mat = -1; uint32_t r = 0;
+        uint32_t r = 0;
         for (int k = 0; k < l; k++) {
-            r = g.rec[(size_t)k * g.N + c];
-            if (k < l - 1) g.prv[(size_t)k * g.N + c] = (uint8_t)(k > 0 ? k - 1 : LINK_NONE);
-            if (rec_hole(r)) continue;
-            const uint32_t want = (r & ~REC_RUN) | ((below_mat == rec_mat(r)) ? REC_RUN : 0u);
-            if (want != r) { r = want; g.rec[(size_t)k * g.N + c] = r; }
-            below_mat = rec_mat(r);
+            const size_t at = (size_t)k * g.N + c;
+            const uint32_t old = g.rec[at];
+            r = (old & REC_BODY & ~REC_MARK) | ((uint32_t)(k > 0 ? k - 1 : LNK_NONE) << LNK_SHIFT);
+            if (r != old && k < l - 1) g.rec[at] = r;
         }
-        g.top[c] = l > 0 ? r : 0;
-        g.link[c] = (uint8_t)(l > 1 ? l - 2 : LINK_NONE);
+        g.top[c] = r;
     }
 }
 

@@ -66,7 +66,7 @@ struct Elastic {
 
 struct Snapshot {
     uint8_t* len = nullptr; uint32_t* rec = nullptr; uint32_t* top = nullptr;
-    uint8_t* link = nullptr; uint8_t* prv = nullptr; int nextp = 0;
+    int nextp = 0;
     int planes = 0;                                       // planes copied (the ones in use when it was taken)
     bool split = true, len_valid = true;
     int lmax = 0; int lmax_vis = 0; int len_bound = 0; bool has_gaps = false, has_cavity = false;
@@ -93,11 +93,10 @@ struct cg_grid {
     uint8_t* len = nullptr; uint32_t* rec = nullptr;      // see cg_kernels.hip.h for the layout
     uint32_t* top = nullptr;                              // split form: top interval of every column
     uint32_t* top_alt = nullptr;                          // the buffer a lateral step writes its new tops to (then swapped)
-    uint8_t* link = nullptr; uint8_t* prv = nullptr;      // split form: chain of a column's intervals through the planes
     int nextp = 0;                                        // split form: first plane no interval lives in yet
     bool split = true;                                    // which form the columns are in right now
     bool len_valid = true;                                // split form: len[] agrees with the chains (see ensure_len)
-    bool pristine = false;                                // every column is empty, but len / top / link still hold old bytes (see zero_planes)
+    bool pristine = false;                                // every column is empty, but len / top still hold old bytes (see zero_planes)
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::vector<uint8_t*> masks;
     std::vector<int8_t> mask_any;                         // per mask: does it open any column of this handle (-1: not looked at yet)
@@ -127,8 +126,8 @@ struct cg_grid {
     bool halo_external = false;
     // etch_wet / deposit_ALD write a second set of planes (ALD's cavity merge a third) and swap
     uint8_t* alt_len[2] = {nullptr, nullptr}; uint32_t* alt_rec[2] = {nullptr, nullptr}; int alt_lmax[2] = {0, 0};
-    // rec (the grid's and the two spare sets') and prv live in elastic buffers; rec / prv / alt_rec are their bases
-    Elastic rec_el, prv_el, alt_el[2];
+    // rec (the grid's and the two spare sets') live in elastic buffers; rec / alt_rec are their bases
+    Elastic rec_el, alt_el[2];
     int plane_budget = 256;                                // most planes the handle may map before it compacts instead (cg_set_plane_budget)
     // deposit_ALD: seeds of the exposed faces (plane-major like the grid), their bounding box, the tap table
     uint16_t* seed_n = nullptr; uint2* seed = nullptr; int seed_planes = 0; bool has_seeds = false;
@@ -201,7 +200,7 @@ int js_to_int32(double v) {                  // (v | 0)
 GridView view(const cg_grid* g) {
     GridView v;
     v.len = g->len; v.rec = g->rec; v.top = g->top; v.top_w = g->top; v.split = g->split ? 1 : 0;
-    v.link = g->link; v.prv = g->prv; v.P = -1;
+    v.P = -1;
     v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.tile_i0 = 0; v.tile_in = 0; v.sup_i = 1; v.sup_j = 1; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
     return v;
 }
@@ -287,14 +286,14 @@ void el_free(Elastic& e) {
 }
 
 constexpr int MAX_PLANES = 256;
+constexpr int SPLIT_PLANES = LNK_NONE;                  // planes a record's link can name: the split form holds columns of up to SPLIT_PLANES + 1 intervals
 
 void free_planes(cg_grid* g) {
     if (g->len) (void)hipFree(g->len);
     if (g->top) (void)hipFree(g->top);
     if (g->top_alt) (void)hipFree(g->top_alt);
-    if (g->link) (void)hipFree(g->link);
-    el_free(g->rec_el); el_free(g->prv_el);
-    g->len = nullptr; g->rec = nullptr; g->top = nullptr; g->top_alt = nullptr; g->link = nullptr; g->prv = nullptr;
+    el_free(g->rec_el);
+    g->len = nullptr; g->rec = nullptr; g->top = nullptr; g->top_alt = nullptr;
     g->lmax = 0;
 }
 
@@ -305,21 +304,18 @@ int alloc_planes(cg_grid* g, int lmax) {
         HIPCHK(g, hipMalloc(&g->len, std::max<size_t>(g->N, 4)));
         HIPCHK(g, hipMalloc(&g->top, std::max<size_t>(4 * g->N, 16)));
         HIPCHK(g, hipMalloc(&g->top_alt, std::max<size_t>(4 * g->N, 16)));
-        HIPCHK(g, hipMalloc(&g->link, std::max<size_t>(g->N, 16)));
     }
     int rc = el_reserve(g, g->rec_el, 4 * g->N * (size_t)MAX_PLANES, 4 * g->N * 16); if (rc) return rc;        // chunks of 16 planes
-    rc = el_reserve(g, g->prv_el, g->N * (size_t)MAX_PLANES, g->N * 16); if (rc) return rc;
     rc = el_resize(g, g->rec_el, 4 * g->N * (size_t)lmax); if (rc) return rc;
-    rc = el_resize(g, g->prv_el, g->N * (size_t)lmax); if (rc) return rc;
-    g->rec = (uint32_t*)g->rec_el.base; g->prv = (uint8_t*)g->prv_el.base;
+    g->rec = (uint32_t*)g->rec_el.base;
     g->lmax = lmax;
     return CG_OK;
 }
 
 // Empty every column.  Nothing is cleared here: the grid is marked pristine, and either the next
-// step is a deposit without a mask -- then the kernel treats every column as empty and writes top and
-// link of all of them itself -- or whatever touches the columns first clears len / top / link
-// (materialize).  Plane slots hold unspecified data anyway and nothing reads them.
+// step is a deposit without a mask -- then the kernel treats every column as empty and writes the top
+// of all of them itself -- or whatever touches the columns first clears len / top (materialize).
+// Plane slots hold unspecified data anyway and nothing reads them.
 int zero_planes(cg_grid* g, bool all = true) {
     (void)all;
     g->pristine = true;
@@ -332,7 +328,6 @@ int materialize(cg_grid* g) {
     ProfScope ps(g, CG_K_CLEAR);
     HIPCHK(g, hipMemsetAsync(g->len, 0, g->N, g->stream));
     HIPCHK(g, hipMemsetAsync(g->top, 0, 4 * g->N, g->stream));
-    HIPCHK(g, hipMemsetAsync(g->link, 0xff, g->N, g->stream));        // LINK_NONE: nothing below
     g->pristine = false; g->len_valid = true;
     return CG_OK;
 }
@@ -353,7 +348,9 @@ int ensure_len(cg_grid* g) {
 }
 int ensure_split(cg_grid* g) {
     if (g->split) return CG_OK;
-    if (g->len_bound > g->lmax) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; }
+    if (g->len_bound > std::min(g->lmax, SPLIT_PLANES + 1)) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; }
+    if (g->len_bound > SPLIT_PLANES + 1)
+        return fail(g, CG_ERR_UNSUPPORTED, "a column holds %d intervals, the vertical and lateral steps take at most %d", g->len_bound, SPLIT_PLANES + 1);
     ProfScope ps(g, CG_K_OTHER);
     hipLaunchKernelGGL(k_promote, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g));
     HIPCHK(g, hipGetLastError());
@@ -378,8 +375,7 @@ int grow_planes(cg_grid* g, int add = 16) {
     const int newL = std::min(MAX_PLANES, g->lmax + add);
     if (newL == g->lmax) return CG_OK;
     int rc = el_resize(g, g->rec_el, 4 * g->N * (size_t)newL); if (rc) return rc;
-    rc = el_resize(g, g->prv_el, g->N * (size_t)newL); if (rc) return rc;
-    g->rec = (uint32_t*)g->rec_el.base; g->prv = (uint8_t*)g->prv_el.base;       // (unchanged unless the device lacks VMM)
+    g->rec = (uint32_t*)g->rec_el.base;                     // (unchanged unless the device lacks virtual memory management)
     g->lmax = newL;
     return CG_OK;
 }
@@ -392,7 +388,6 @@ int trim_planes(cg_grid* g) {
     const int want = std::max(std::min(g->lmax_vis, MAX_PLANES), (g->len_bound + 15) / 16 * 16);
     if (want + 16 > g->lmax) return CG_OK;
     rc = el_resize(g, g->rec_el, 4 * g->N * (size_t)want); if (rc) return rc;
-    rc = el_resize(g, g->prv_el, g->N * (size_t)want); if (rc) return rc;
     g->lmax = want;
     return CG_OK;
 }
@@ -402,7 +397,7 @@ int trim_planes(cg_grid* g) {
 bool memory_allows_planes(cg_grid* g, int add) {
     size_t fr = 0, to = 0;
     if (hipMemGetInfo(&fr, &to) != hipSuccess) { (void)hipGetLastError(); return false; }
-    const size_t plane = 5 * g->N;
+    const size_t plane = 4 * g->N;
     return fr > plane * (size_t)add + plane * (size_t)std::max(g->len_bound, 16) + to / 16;
 }
 
@@ -574,16 +569,19 @@ int ensure_stencil_scratch(cg_grid* g, int R, bool need_halo) {
 // columns are compacted (whole form and back: interval k in plane k), which frees every plane
 // above max(len)-2 at the price of moving every interval.
 int take_append_plane(cg_grid* g, int* P) {
-    const int cap = std::min(std::min(g->plane_budget, MAX_PLANES), 255);          // (255 = LINK_NONE is never a link)
-    if (g->nextp >= std::min(g->lmax, 255)) {
+    // planes come in chunks of 16, a link names planes 0 .. SPLIT_PLANES-1: the cap is 64 planes of which 63 are usable
+    const int cap = std::min(std::min(g->plane_budget, MAX_PLANES), (SPLIT_PLANES + 15) / 16 * 16);
+    const auto usable = [&]() { return std::min(g->lmax, SPLIT_PLANES); };
+    if (g->nextp >= usable()) {
         if (g->lmax + 16 <= cap && memory_allows_planes(g, 16)) {
             int rc = grow_planes(g); if (rc) return rc;                          // in place, nothing moves
         } else {
             int rc = ensure_whole(g); if (rc) return rc;
             rc = refresh_len_bound(g, nullptr); if (rc) return rc;
             rc = ensure_split(g); if (rc) return rc;
-            if (g->nextp >= std::min(g->lmax, 255)) { rc = grow_planes(g); if (rc) return rc; }
-            if (g->nextp >= std::min(g->lmax, 255)) return fail(g, CG_ERR_UNSUPPORTED, "a column holds more than 255 intervals");
+            if (g->nextp >= usable() && g->lmax < SPLIT_PLANES) { rc = grow_planes(g); if (rc) return rc; }      // the columns need them, budget or not
+            if (g->nextp >= usable())
+                return fail(g, CG_ERR_UNSUPPORTED, "a column holds more than %d intervals", SPLIT_PLANES);
         }
     }
     *P = g->nextp++;
@@ -890,7 +888,7 @@ static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, 
     if (g->stats_on) { if (U == 1) LV(true, 1); else if (U == 2) LV(true, 2); else LV(true, 4); }
     else { if (U == 1) LV(false, 1); else if (U == 2) LV(false, 2); else LV(false, 4); }
 #undef LV
-    if (fresh) g->pristine = false;          // top and link are defined now; len is behind as after any such launch
+    if (fresh) g->pristine = false;          // the tops are defined now; len is behind as after any such launch
 }
 
 // =============================================================================================
@@ -953,7 +951,7 @@ int cg_destroy(cg_grid* g) {
     free_planes(g);
     for (auto m : g->masks) if (m) (void)hipFree(m);
     for (auto k : g->kcache) free_kernel(k);
-    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.rec); (void)hipFree(s.second.top); (void)hipFree(s.second.link); (void)hipFree(s.second.prv); }
+    for (auto& s : g->snaps) { (void)hipFree(s.second.len); (void)hipFree(s.second.rec); (void)hipFree(s.second.top); }
     if (!g->halo_external) for (auto h : g->halo) if (h) (void)hipFree(h);
     for (auto& r : g->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
@@ -1229,7 +1227,7 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     const double S = std::isnan(conformality) ? 0.0 : std::max(0.0, std::min(1.0, conformality));   // cg1:440, 603
     const double latRange = t * S;
     // a reset grid whose first step is a deposit everywhere needs no clearing pass: the kernel writes
-    // top and link of every column itself
+    // top of every column itself
     const bool fresh = g->pristine && kind == CG_STENCIL_DEPOSIT && latRange < std::min(g->dx, g->dy) && !mask && g->N % 4 == 0 && g->lmax >= 1;
     if (!fresh) { int rcm = materialize(g); if (rcm) return rcm; }
     { int rcs = ensure_split(g); if (rcs) return rcs; }
@@ -2008,9 +2006,6 @@ int cg_snapshot_save(cg_grid* g, int slot) {
     const size_t S = g->N * (size_t)s.planes;
     HIPCHK(g, hipMalloc(&s.len, std::max<size_t>(g->N, 4))); HIPCHK(g, hipMalloc(&s.rec, std::max<size_t>(4 * S, 4)));
     HIPCHK(g, hipMalloc(&s.top, std::max<size_t>(4 * g->N, 16)));
-    HIPCHK(g, hipMalloc(&s.link, std::max<size_t>(g->N, 16))); HIPCHK(g, hipMalloc(&s.prv, std::max<size_t>(S, 16)));
-    HIPCHK(g, hipMemcpyAsync(s.link, g->link, g->N, hipMemcpyDeviceToDevice, g->stream));
-    if (S) HIPCHK(g, hipMemcpyAsync(s.prv, g->prv, S, hipMemcpyDeviceToDevice, g->stream));
     s.nextp = g->nextp;
     HIPCHK(g, hipMemcpyAsync(s.len, g->len, g->N, hipMemcpyDeviceToDevice, g->stream));
     if (S) HIPCHK(g, hipMemcpyAsync(s.rec, g->rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
@@ -2032,8 +2027,6 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     HIPCHK(g, hipMemcpyAsync(g->len, s.len, g->N, hipMemcpyDeviceToDevice, g->stream));
     if (S) HIPCHK(g, hipMemcpyAsync(g->rec, s.rec, 4 * S, hipMemcpyDeviceToDevice, g->stream));
     HIPCHK(g, hipMemcpyAsync(g->top, s.top, 4 * g->N, hipMemcpyDeviceToDevice, g->stream));
-    HIPCHK(g, hipMemcpyAsync(g->link, s.link, g->N, hipMemcpyDeviceToDevice, g->stream));
-    if (S) HIPCHK(g, hipMemcpyAsync(g->prv, s.prv, S, hipMemcpyDeviceToDevice, g->stream));
     g->nextp = s.nextp;
     g->split = s.split;
     g->len_bound = s.len_bound; g->has_gaps = s.has_gaps; g->has_cavity = s.has_cavity;
@@ -2047,7 +2040,6 @@ int cg_snapshot_drop(cg_grid* g, int slot) {
     if (it == g->snaps.end()) return CG_OK;
     HIPCHK(g, hipStreamSynchronize(g->stream));
     (void)hipFree(it->second.len); (void)hipFree(it->second.rec); (void)hipFree(it->second.top);
-    (void)hipFree(it->second.link); (void)hipFree(it->second.prv);
     g->snaps.erase(it);
     return CG_OK;
 }

@@ -4,7 +4,7 @@ It offers the same stencil_begin / stencil_finish / set_halo_buffers surface as
 fem_amd.ColumnGrid, implemented with the CPU oracle, and speaks the same wire formats: halo =
 R*ny u16 top heights followed by R*ny u8 etchable flags per direction; ghost row = len[ny]
 (padded to 4 bytes) followed by rec[planes][ny] u32 records z1q | mat << 16 | flags << 24
-(flags: 1 gap, 2 flood mark, 8 layer), a gap being an interval of its own."""
+(flags: 1 gap, 2 layer, 4 flood mark), a gap being an interval of its own."""
 import ctypes
 import math
 
@@ -282,7 +282,7 @@ class OracleSlabEngine:
         for k in range(ln[c]):
             if zp[c, k, 0] > prev:
                 out.append((int(zp[c, k, 0]), 0, 1))
-            fl = 8 | (2 if marks is not None and marks[c, k] else 0)
+            fl = 2 | (4 if marks is not None and marks[c, k] else 0)
             out.append((int(zp[c, k, 1]), int(mat[c, k]), fl))
             prev = int(zp[c, k, 1])
         return out
@@ -313,7 +313,7 @@ class OracleSlabEngine:
             for p in range(min(int(buf[j]), planes)):
                 r = int(rec[p, j]); z1 = r & 0xFFFF; fl = r >> 24
                 if not (fl & 1):
-                    lay.append((prev, z1, (r >> 16) & 255, bool(fl & 2)))
+                    lay.append((prev, z1, (r >> 16) & 255, bool(fl & 4)))
                 prev = z1
             cols.append(lay)
         return cols
