@@ -61,6 +61,7 @@ struct GridView {
     int       tile_i0;  // lateral steps: first tile row of this launch (a launch may cover a band of tile rows)
     int       tile_in;  // lateral steps: tile rows of this launch
     int       sup_i, sup_j;   // lateral steps: tiles per super-tile (see tile_of_block)
+    int       ti;       // lateral steps, streaming form: rows per tile
     double    zs;       // nm per step
     double    inv_zs;   // 1/zs, rounded once on the host
 };
@@ -355,6 +356,17 @@ __device__ __forceinline__ void load_below4(const GridView& g, size_t c0, unsign
         } else {
             b[j0] = g.rec[at + j0];
         }
+    }
+}
+
+// The same records by four one-column loads that are issued back to back and nothing waits for (load_below4's
+// loop consumes each load before it issues the next): the form for a kernel that has other work to do meanwhile.
+// A column without an interval below reads plane 0 instead, and the value is not looked at.
+__device__ __forceinline__ void load_below4_flat(const GridView& g, size_t c0, const u32x4 tv, uint32_t (&b)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = rec_lnk(tv[j]);
+        b[j] = g.rec[(size_t)(p != LNK_NONE ? p : 0) * g.N + c0 + j];
     }
 }
 
@@ -890,6 +902,279 @@ __global__ __launch_bounds__(256) void k_stencil_sym(GridView g, const uint8_t* 
         if (ETCH) { const int slot[4] = {ST_OPEN, ST_ETCHED, ST_REMOVED, ST_FLOOR}; stats_commit<4>(gstats, loc, slot); }
         else { const int slot[4] = {ST_OPEN, ST_EXTEND, ST_APPEND, ST_FLOOR}; stats_commit<4>(gstats, loc, slot); }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// lateral-stencil steps, row-streaming form (radius known at compile time)
+// ------------------------------------------------------------------------------------------
+// One wave owns a strip of STRIP columns (4 per lane) and walks down the rows of its tile.  Every
+// input row is staged once (one LDS row, read back with its halo columns) and SCATTERS into the
+// 2R+1 output rows it reaches, instead of every output row gathering 2R+1 input rows:
+//   p[dv]   = op(h[j+dv], h[j-dv])                       shared by every du          (R ops per column)
+//   D[du]   = op over dv of (p[dv] + a(du, dv))          serves output rows r-du and r+du
+//   A[k]    = op(A[k+1], D[|R-k|]),  A[2R] = D[R]        the running results of the output rows centred
+//                                                        on input rows r-R .. r+R; the shift through the
+//                                                        registers rides on the three-operand op
+// After input row r the output row centred on r-R is complete (A[0]) and is updated like in
+// k_stencil_sym.  About 200 vector instructions per input row and 4 columns at R = 5, against
+// 340 for the gathering form, one LDS row write and W/4 reads per row instead of (2R+1) W/4 reads,
+// and halo rows are staged once per ti rows.  Same arithmetic (float adds, integer op on the bit
+// patterns, see k_stencil_sym), only the order of the maxima differs, which cannot change them.
+constexpr int STRIP = 256;
+template <int R> struct StreamGeom {
+    static constexpr int Rp = (R + 3) & ~3;          // halo columns rounded up to whole groups
+    static constexpr int PITCH = STRIP + 2 * Rp;     // floats per staged row
+    static constexpr int W = 4 + 2 * Rp;             // floats a lane reads per row
+    static constexpr int HG = Rp / 4;                // halo groups on each side of the strip
+};
+
+// 4 consecutive columns of a staged row: top records and mask bytes.  A row of a neighbour's message
+// (u16 heights + flag bytes) is turned into records of the step's material on arrival, so that one
+// code path stages both; such rows are few (the R rows next to a slab edge).
+struct RawGroup { u32x4 a; unsigned m; };
+
+// MSG = false: the tile reaches no neighbour's rows; rows beyond the slab repeat its edge row
+// (cg1:381-387) with flags zero (cg1:671).  No branch: every lane always issues the same two loads.
+template <bool ETCH, bool MSG, bool MASKED>
+__device__ __forceinline__ RawGroup stream_load(const GridView& g, const uint8_t* __restrict__ mask, int il, int Rimg, size_t msg_n, int jc, int matId,
+                                                const uint8_t* __restrict__ halo_lo, const uint8_t* __restrict__ halo_up) {
+    RawGroup o; o.a = (u32x4)(0); o.m = 0;
+    if (MSG) {
+        const RowSrc src = row_source(g, il, Rimg, halo_lo, halo_up);
+        if (src.msg) {
+            if (src.row >= 0 && src.row < Rimg) {
+                const size_t p = (size_t)src.row * g.ny + jc;
+                const uint2 h = *(const uint2*)((const uint16_t*)src.msg + p);
+                o.a[0] = rec_make(h.x & 0xffffu, matId); o.a[1] = rec_make(h.x >> 16, matId);
+                o.a[2] = rec_make(h.y & 0xffffu, matId); o.a[3] = rec_make(h.y >> 16, matId);
+                if (ETCH) o.m = *(const unsigned*)(src.msg + 2 * msg_n + p);
+            }
+            return o;
+        }
+    }
+    const bool edge = il < 0 || il >= g.nx;
+    const size_t p = (size_t)(il < 0 ? 0 : (il >= g.nx ? g.nx - 1 : il)) * g.ny + jc;
+    o.a = ld_rec4(g.top + p);
+    if (ETCH) {
+        if (MASKED) { const unsigned w = *(const unsigned*)(mask + p); o.m = edge ? 0u : w; }      // (loaded either way: no branch)
+        else o.m = edge ? 0u : 0x01010101u;
+    }
+    return o;
+}
+
+// float32(q*zscale) (cg1:465) of a raw group; left / right: the group lies beyond the first / last
+// column and repeats the edge column (cg1:374-380); not-etchable cells become +inf (cg1:718)
+template <bool ETCH>
+__device__ __forceinline__ float4 stream_heights(const GridView& g, const RawGroup& w, bool left, bool right, int matId, bool isAll) {
+    unsigned q[4], e = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        q[c] = rec_z1(w.a[c]);
+        if (ETCH && ((w.m >> (8 * c)) & 0xffu) && etchable(w.a[c], matId, isAll)) e |= 1u << c;
+    }
+    if (left) { q[1] = q[0]; q[2] = q[0]; q[3] = q[0]; }
+    if (right) { q[0] = q[3]; q[1] = q[3]; q[2] = q[3]; }
+    float4 h;
+    h.x = (float)((double)q[0] * g.zs); h.y = (float)((double)q[1] * g.zs);
+    h.z = (float)((double)q[2] * g.zs); h.w = (float)((double)q[3] * g.zs);
+    if (ETCH) {
+        const float INF = __builtin_inff();
+        if (left || right) e = 0;
+        if (!(e & 1u)) h.x = INF; if (!(e & 2u)) h.y = INF; if (!(e & 4u)) h.z = INF; if (!(e & 8u)) h.w = INF;
+    }
+    return h;
+}
+
+// Could entry (du, dv) of the quadrant table lie inside the ellipse of a kernel of radius R?  The
+// ellipse is a circle of radius rho in cells, R <= rho < R+1.  Entries that cannot are skipped at
+// compile time; the others are all evaluated (those outside a particular kernel hold -inf, the
+// identity of the op), which keeps the loop body free of branches.
+constexpr bool stream_entry(int R, int du, int dv) { return du * du + dv * dv < (R + 1) * (R + 1); }
+constexpr int STREAM_TAB_PITCH = 12;                // floats per table row in LDS (R + 1 <= 9, rounded up to whole float4s)
+
+template <bool B> struct BoolTag { static constexpr bool value = B; };
+
+// Block = one wave.  Tile = g.ti rows x STRIP columns; tile_of_block names it.
+// quad: the (R+1) x (R+1) quadrant table in device memory (symmetric, since dx == dy).
+template <int R, bool ETCH, bool MSG, bool MASKED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_stencil_stream(GridView g, const uint8_t* __restrict__ mask, int matId, double t, int Rimg,
+                                                       const uint8_t* __restrict__ halo_lo, const uint8_t* __restrict__ halo_up,
+                                                       const float* __restrict__ quad, int* __restrict__ flags, unsigned long long* gstats) {
+    using G = StreamGeom<R>;
+    constexpr int Rp = G::Rp, PITCH = G::PITCH, W = G::W, HG = G::HG, TP = STREAM_TAB_PITCH;
+    __shared__ __align__(16) float s_row[2][PITCH];
+    __shared__ __align__(16) float s_tab[(R + 1) * TP];
+    const int tiles_j = (g.ny + STRIP - 1) / STRIP;
+    int tile_i, tile_j;
+    if (!tile_of_block(g, tiles_j, tile_i, tile_j)) return;
+    const int i_base = tile_i * g.ti, j_base = tile_j * STRIP;
+    const int rows_out = min(g.ti, g.nx - i_base);
+    const int rows_in = rows_out + 2 * R;
+    const int lane = threadIdx.x;
+    const int j0 = j_base + 4 * lane;
+    const bool isAll = (matId == 255);
+    const size_t msg_n = (size_t)Rimg * g.ny;
+    for (int e = lane; e < (R + 1) * TP; e += 64) {
+        const int dv = e / TP, du = e - dv * TP;
+        s_tab[e] = du <= R ? quad[dv * (R + 1) + du] : -__builtin_inff();
+    }
+    // this lane's own group (beyond the last column it repeats the edge: it is halo of the lanes before it) ...
+    const bool m_right = j0 >= g.ny;
+    const int m_jc = m_right ? g.ny - 4 : j0;
+    // ... and, for the first 2 HG lanes, one halo group left or right of the strip
+    const bool has_halo = lane < 2 * HG;
+    const bool h_upper = lane >= HG;
+    const int hj = h_upper ? j_base + STRIP + 4 * (lane - HG) : j_base - Rp + 4 * lane;
+    const bool h_left = hj < 0, h_right = hj >= g.ny;
+    const int h_jc = h_left ? 0 : (h_right ? g.ny - 4 : hj);
+    const int h_at = h_upper ? Rp + STRIP + 4 * (lane - HG) : 4 * lane;
+
+    float A[2 * R + 1][4];
+#pragma unroll
+    for (int k = 0; k <= 2 * R; k++) { A[k][0] = 0.f; A[k][1] = 0.f; A[k][2] = 0.f; A[k][3] = 0.f; }
+    unsigned loc[4] = {0, 0, 0, 0};      // (statistics are not kept by this form: with them enabled the host runs k_stencil_sym)
+
+    // Software pipeline.  While the taps of input row r are evaluated (the long part), the loads of row r+2
+    // and of the columns of the next output row are in flight, and the stores of the output row before
+    // are draining: the one wait on vector memory in an iteration comes after the taps.
+    RawGroup in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R, Rimg, msg_n, m_jc, matId, halo_lo, halo_up), in_h;
+    in_h.a = (u32x4)(0); in_h.m = 0;
+    if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
+    *(float4*)(s_row[0] + Rp + 4 * lane) = stream_heights<ETCH>(g, in_m, false, m_right, matId, isAll);
+    if (has_halo) *(float4*)(s_row[0] + h_at) = stream_heights<ETCH>(g, in_h, h_left, h_right, matId, isAll);
+    if (1 < rows_in) {
+        in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + 1, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);
+        if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + 1, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
+    }
+
+#define CG_OP(a, b) __int_as_float(ETCH ? min(__float_as_int(a), __float_as_int(b)) : max(__float_as_int(a), __float_as_int(b)))
+    // One input row.  FIN: the row completes an output row (every row from the 2R-th on), which is then updated.
+    // The two cases are separate loops so that in the second one every path consumes what it loads: a load whose
+    // use sits in a branch makes the compiler wait for ALL vector memory traffic -- the stores of the row
+    // before included -- at the loop head.
+    auto step = [&](const int r, auto fin_tag) __attribute__((always_inline)) {
+        constexpr bool FIN = decltype(fin_tag)::value;
+        const float* buf = s_row[r & 1];
+        // The wave's LDS accesses execute in order, and the compiler keeps stores and loads of the one array in
+        // program order: no fence is needed between the store of a row and its loads by other lanes of the wave.
+        __builtin_amdgcn_wave_barrier();
+        float hc[W];
+        {
+            const float* rowc = buf + 4 * lane;
+#pragma unroll
+            for (int k = 0; k < W / 4; k++) { const float4 v = *(const float4*)(rowc + 4 * k); hc[4 * k] = v.x; hc[4 * k + 1] = v.y; hc[4 * k + 2] = v.z; hc[4 * k + 3] = v.w; }
+        }
+        // the columns of the output row that this input row completes: needed after the taps (lanes beyond the
+        // last column load a copy of the edge group: every lane takes part, only their stores are left out)
+        const size_t c0 = (size_t)(i_base + (FIN ? r - 2 * R : 0)) * g.ny + m_jc;
+        u32x4 tv = (u32x4)(0); unsigned mk = 0x01010101u;
+        if (FIN) { tv = ld_rec4(g.top + c0); if (MASKED) mk = *(const unsigned*)(mask + c0); }
+        // ---- D[du] = op over dv of (p[dv] + a(du, dv)); row dv of the (symmetric) table lists the du's
+        float D[R + 1][4];
+#pragma unroll
+        for (int dv = 0; dv <= R; dv++) {
+            float p[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) p[c] = dv == 0 ? hc[Rp + c] : CG_OP(hc[Rp + c + dv], hc[Rp + c - dv]);
+            float a[TP];
+#pragma unroll
+            for (int k = 0; k < (R + 4) / 4; k++) { const float4 v = *(const float4*)(s_tab + dv * TP + 4 * k); a[4 * k] = v.x; a[4 * k + 1] = v.y; a[4 * k + 2] = v.z; a[4 * k + 3] = v.w; }
+#pragma unroll
+            for (int du = 0; du <= R; du++) {
+                if (!stream_entry(R, du, dv)) continue;
+                f32x2 x01 = {p[0], p[1]}, x23 = {p[2], p[3]};
+                const f32x2 aa = {a[du], a[du]};
+                x01 = ETCH ? x01 - aa : x01 + aa; x23 = ETCH ? x23 - aa : x23 + aa;
+                if (dv == 0) { D[du][0] = x01[0]; D[du][1] = x01[1]; D[du][2] = x23[0]; D[du][3] = x23[1]; }
+                else { D[du][0] = CG_OP(D[du][0], x01[0]); D[du][1] = CG_OP(D[du][1], x01[1]); D[du][2] = CG_OP(D[du][2], x23[0]); D[du][3] = CG_OP(D[du][3], x23[1]); }
+            }
+        }
+        // ---- every output row in reach takes its D; slot k moves to slot k-1 on the way
+#pragma unroll
+        for (int k = 0; k < 2 * R; k++) {
+            const int du = k < R ? R - k : k - R;
+#pragma unroll
+            for (int c = 0; c < 4; c++) A[k][c] = CG_OP(A[k + 1][c], D[du][c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) A[2 * R][c] = D[R][c];
+        // (the taps stay here, before the wait on vector memory below: without this the compiler sinks them past it)
+#pragma unroll
+        for (int k = 0; k <= 2 * R; k++) { asm volatile("" : "+v"(A[k][0]), "+v"(A[k][1]), "+v"(A[k][2]), "+v"(A[k][3])); }
+        // ---- the output row centred on input row r - R is complete in A[0]: which of its columns take part
+        // (The output row's columns arrive here on every path: a use that sat only inside the branches below would
+        // leave them "maybe pending" at the loop head and cost a wait for everything there.)
+        if (FIN) asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(mk));
+        unsigned act = 0;
+        uint32_t b4[4] = {0, 0, 0, 0};
+        if (FIN) {
+            act = ((mk & 0xffu) ? 1u : 0u) | ((mk & 0xff00u) ? 2u : 0u) | ((mk & 0xff0000u) ? 4u : 0u) | ((mk & 0xff000000u) ? 8u : 0u);
+            if (ETCH) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) if (!etchable(tv[c], matId, isAll)) act &= ~(1u << c);
+            }
+            if (m_right) act = 0;
+            // etch: every etchable column needs the interval below its top (floor and cut); the loads travel while row r+1 is staged
+            if (ETCH && act) load_below4_flat(g, c0, tv, b4);
+        }
+        // ---- stage input row r+1
+        if (r + 1 < rows_in) {
+            float* nxt = s_row[(r + 1) & 1];
+            *(float4*)(nxt + Rp + 4 * lane) = stream_heights<ETCH>(g, in_m, false, m_right, matId, isAll);
+            if (has_halo) *(float4*)(nxt + h_at) = stream_heights<ETCH>(g, in_h, h_left, h_right, matId, isAll);
+        }
+        // (the records loaded above are looked at from here on, not before the staging)
+        if (ETCH && FIN) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
+        // ---- start the loads of row r+2.  Deposit: now, the update below loads nothing.  Etch: after the update, whose
+        // waits for its own loads would otherwise wait for these as well.
+        if (!(ETCH && FIN) && r + 2 < rows_in) {
+            in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);
+            if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
+        }
+        // ---- the update of the output row
+        if (FIN) {
+            bool stored = false;
+            if (act) {
+                float own[4], m[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    own[c] = (float)((double)rec_z1(tv[c]) * g.zs);
+                    const float init = ETCH ? (float)((double)own[c] - t) : (float)((double)own[c] + t);     // cg1:702 / cg1:499
+                    m[c] = CG_OP(A[0][c], init);
+                }
+                double dz[4] = {0, 0, 0, 0};
+                unsigned open = 0;
+                if (!ETCH) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (!((act >> c) & 1)) continue;
+                        const double d = (double)m[c] - (double)own[c];          // cg1:534-537
+                        if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
+                    }
+                    if (open) stored = depo_group4<false>(g, c0, open, dz, matId, tv, loc[1], loc[2]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (!((act >> c) & 1)) continue;
+                        float F = 0.f;                                           // floor = bottom of the top run of matId (cg1:646-660)
+                        if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, matId, tv[c], b4[c], loc[3]));
+                        const float hpv = fmaxf(0.f, fmaxf(F, m[c]));            // cg1:725
+                        const double d = (double)own[c] - (double)hpv;
+                        if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
+                    }
+                    if (open) stored = etch_group4<false>(g, c0, open, dz, matId, isAll, tv, act, b4, loc[1], loc[2]);
+                }
+            }
+            if (!stored && !m_right && g.top_w != g.top) st_rec4(g.top_w + c0, tv);          // columns that stay as they are
+        }
+        if (ETCH && FIN && r + 2 < rows_in) {
+            in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);
+            if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
+        }
+    };
+    for (int r = 0; r < 2 * R; r++) step(r, BoolTag<false>{});
+    for (int r = 2 * R; r < rows_in; r++) step(r, BoolTag<true>{});
+#undef CG_OP
 }
 
 // ------------------------------------------------------------------------------------------

@@ -34,6 +34,16 @@ static int sym_tile_cols(int Re) {
     return v ? v : (Re <= 2 ? 128 : 64);
 }
 
+// the row-streaming lateral kernel: smallest radius it takes (env CG_STREAM_MINR; 9 = never) and rows per tile (env CG_STREAM_TI)
+static int stream_min_radius() {
+    static int v = [] { const char* e = getenv("CG_STREAM_MINR"); int x = e ? atoi(e) : 3; return (x >= 1 && x <= 9) ? x : 3; }();
+    return v;
+}
+static int stream_tile_rows() {
+    static int v = [] { const char* e = getenv("CG_STREAM_TI"); int x = e ? atoi(e) : 64; return (x >= 8 && x <= 4096) ? x : 64; }();
+    return v;
+}
+
 namespace {
 
 thread_local std::string t_create_error;
@@ -53,6 +63,7 @@ struct ConfKernel {
     int Re = 0; bool sym_ok = false;
     std::vector<float> quad;                     // (Re+1)^2 increments, -inf = not a float32 tap
     Tap* d_taps64_sym = nullptr; int ntaps64_sym = 0;
+    float* d_quad = nullptr;                     // the quadrant table on the device (k_stencil_stream)
 };
 
 // A device buffer that grows and shrinks in place: a reserved address range of which a prefix is
@@ -201,7 +212,7 @@ GridView view(const cg_grid* g) {
     GridView v;
     v.len = g->len; v.rec = g->rec; v.top = g->top; v.top_w = g->top; v.split = g->split ? 1 : 0;
     v.P = -1;
-    v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.tile_i0 = 0; v.tile_in = 0; v.sup_i = 1; v.sup_j = 1; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
+    v.N = g->N; v.nx = g->nx; v.ny = g->ny; v.lmax = g->lmax; v.i0 = g->i0; v.tile_i0 = 0; v.tile_in = 0; v.sup_i = 1; v.sup_j = 1; v.ti = 0; v.zs = g->zscale; v.inv_zs = 1.0 / g->zscale;
     return v;
 }
 
@@ -456,6 +467,7 @@ void free_kernel(ConfKernel* k) {
     if (k->d_taps) (void)hipFree(k->d_taps);
     if (k->d_taps64) (void)hipFree(k->d_taps64);
     if (k->d_taps64_sym) (void)hipFree(k->d_taps64_sym);
+    if (k->d_quad) (void)hipFree(k->d_quad);
     delete k;
 }
 
@@ -544,6 +556,8 @@ int upload_taps(cg_grid* g, ConfKernel* k, int R) {
             HIPCHK(g, hipMalloc(&k->d_taps64_sym, std::max<size_t>(1, fine_sym.size()) * sizeof(Tap)));
             if (!fine_sym.empty()) HIPCHK(g, hipMemcpy(k->d_taps64_sym, fine_sym.data(), fine_sym.size() * sizeof(Tap), hipMemcpyHostToDevice));
             k->ntaps64_sym = (int)fine_sym.size();
+            if (!k->d_quad) HIPCHK(g, hipMalloc(&k->d_quad, quad.size() * sizeof(float)));
+            HIPCHK(g, hipMemcpy(k->d_quad, quad.data(), quad.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     }
     return CG_OK;
@@ -669,6 +683,43 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
     const dim3 blk(256);
     Band bands[2];
     ProfScope ps(g, etch ? CG_K_STENCIL_ETCH : CG_K_STENCIL_DEPOSIT);
+    if (sym && K->ntaps64_sym == 0 && K->Re >= stream_min_radius() && !g->stats_on) {
+        // row-streaming form: one wave per tile of ti rows x STRIP columns
+        g->len_valid = false;
+        const int ti = stream_tile_rows();
+        gv.ti = ti;
+        // tile rows that reach a neighbour's rows read its message (MSG form), the others never look at one
+        Band bi[2], bb[2];
+        const int n_int = stencil_bands(g->nx, ti, R, halo_lo != nullptr, halo_up != nullptr, PART_INTERIOR, bi);
+        const int n_bnd = stencil_bands(g->nx, ti, R, halo_lo != nullptr, halo_up != nullptr, PART_BOUNDARY, bb);
+        const int tiles_j = (g->ny + STRIP - 1) / STRIP;
+#define STREAM_L(RR, E, M, K_, BAND)                                                                           \
+    do {                                                                                                       \
+        gv.tile_i0 = (BAND).t0; gv.tile_in = (BAND).n; gv.sup_i = 1; gv.sup_j = 1;                             \
+        const dim3 gridS((unsigned)(((long)(BAND).n * tiles_j + 7) / 8 * 8));                                  \
+        hipLaunchKernelGGL((k_stencil_stream<RR, E, M, K_>), gridS, dim3(64), 0, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
+                           K->d_quad, g->d_flags, g->d_stats);                                                 \
+    } while (0)
+#define STREAM(RR, E, K_)                                                                                      \
+    do {                                                                                                       \
+        if (part != PART_BOUNDARY) for (int b_ = 0; b_ < n_int; b_++) STREAM_L(RR, E, false, K_, bi[b_]);      \
+        if (part != PART_INTERIOR) for (int b_ = 0; b_ < n_bnd; b_++) STREAM_L(RR, E, true, K_, bb[b_]);       \
+    } while (0)
+#define STREAM_ES(RR)                                                                                          \
+    do {                                                                                                       \
+        if (etch) { if (mask) STREAM(RR, true, true); else STREAM(RR, true, false); }                          \
+        else { if (mask) STREAM(RR, false, true); else STREAM(RR, false, false); }                             \
+    } while (0)
+        switch (K->Re) {
+        case 1: STREAM_ES(1); break; case 2: STREAM_ES(2); break; case 3: STREAM_ES(3); break; case 4: STREAM_ES(4); break;
+        case 5: STREAM_ES(5); break; case 6: STREAM_ES(6); break; case 7: STREAM_ES(7); break; default: STREAM_ES(8); break;
+        }
+#undef STREAM_ES
+#undef STREAM
+#undef STREAM_L
+        HIPCHK(g, hipGetLastError());
+        return CG_OK;
+    }
     if (sym) {
         g->len_valid = false;
         const int tjs = sym_tile_cols(K->Re);
