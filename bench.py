@@ -8,8 +8,13 @@ column grid per GPU, resident in HBM.  One bench "step" is one process step of t
 to every column (vertical deposit, masked anisotropic etch, conformal deposit or isotropic
 etch); when the flow wraps, the grid is re-created (createNewGrid) inside the timed region, as
 the reference's runtime does at the start of a rebuild (template/script_runtime.js:219-222).
-With N > 1 every rank owns one 16384-row slab of a (16384*N) x 16384 domain (weak scaling) and
-the stencil steps exchange R boundary rows with the neighbouring ranks over RCCL.
+With N > 1 every rank owns one 16384-row slab of a (16384*N) x 16384 domain (weak scaling, the
+default) or, with --scaling strong, 16384/N rows of ONE 16384 x 16384 domain; the stencil steps
+exchange R boundary rows with the neighbouring ranks over RCCL.
+
+The bench checks what it timed: the checksum of the grid after the timed region must equal the
+checksum an untimed pass (other kernel instantiations: the ones that keep statistics) reached at
+the same step of the flow, and an untimed replay of the timed kernels up to that step.
 
 Prints ONE JSON line (rank 0): metric = column updates per second, whole job.
 """
@@ -30,6 +35,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", "--size", type=int, default=16384, help="columns per side per GPU (default 16384)")
     ap.add_argument("--flow", default="c4", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = --n rows per GPU (default), strong = --n rows in all, split over the GPUs")
+    ap.add_argument("--traffic", default=None, help="JSON of PMC-measured HBM bytes per launch (default: newest profiles/r*_traffic.json)")
     ap.add_argument("--cpu-n", type=int, default=2048, help="grid side of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-replicas", type=int, default=16, help="processes of the all-cores CPU baseline (0 = skip it)")
@@ -58,6 +66,24 @@ def build_masks(fem, flows, grid, specs, names, nx, ny, i0, LX, LY, device):
         if not same:
             raise RuntimeError(f"mask {name}: the rasterised shape list differs from the closed form")
     return out
+
+
+def git_blob_hash(path):
+    """The id git gives the file's contents (no repository needed)."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def newest_traffic_file():
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")):
+        m = re.match(r"r(\d+)_traffic\.json$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
 
 
 def cpu_baseline(flows, flow, n):
@@ -132,8 +158,13 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    nxl = ny = args.n
-    nxg = nxl * world
+    ny = args.n
+    if args.scaling == "strong" and world > 1:
+        if args.n % world:
+            raise SystemExit(f"--scaling strong: {args.n} rows do not split evenly over {world} ranks")
+        nxl, nxg = args.n // world, args.n
+    else:
+        nxl, nxg = args.n, args.n * world
     LX, LY = 2.0 * nxg, 2.0 * ny
     flow = flows.FLOWS[args.flow]()
     specs = flows.mask_specs(LX)
@@ -162,13 +193,13 @@ def main():
 
         # ---- pass 0 (untimed): per-step column counts for the algorithmic-byte model
         grid.stats_enable(True)
-        step_bytes = []
+        step_bytes, step_check = [], []
         slab.createNewGrid()
         for s in flow:
             flows.apply_step(slab, s, masks)
             step_bytes.append(flows.algorithmic_bytes(s["kind"], grid.stats()))
+            step_check.append(slab.checksum())
         grid.stats_enable(False)
-        check = slab.checksum()
 
         # ---- warmup
         k = run(args.warmup, 0)
@@ -187,6 +218,18 @@ def main():
             dist.barrier()
         dt = time.perf_counter() - t0
         prof = grid.profile(False)
+        swap_s, halo_b, slab.swap_seconds, slab.halo_bytes = slab.swap_seconds, slab.halo_bytes, 0.0, 0
+
+        # ---- the state the timed region left must be the state of that step of the flow
+        last = (k + args.steps - 1) % len(flow)            # index in the flow of the last timed step
+        check = slab.checksum()
+        slab.createNewGrid()
+        for s in flow[:last + 1]:
+            flows.apply_step(slab, s, masks)
+        replay = slab.checksum()
+        if check != step_check[last] or replay != check:
+            raise SystemExit("bench.py: the grid after the timed region does not match step %d of the flow: timed %016x, "
+                             "untimed pass with statistics %016x, untimed replay %016x" % (last, check, step_check[last], replay))
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -199,8 +242,8 @@ def main():
             t = max(0.0, s["t"]); S = 0.0 if s["kind"] == "SUBSTR" else max(0.0, min(1.0, s["S"]))
             stencil = t * S >= 2.0
             if s["kind"] in ("SUBSTR", "DEPO"):
-                return "k_stencil_sym<deposit>" if stencil else "k_vertical_g4<deposit>"
-            return "k_stencil_sym<etch>" if stencil else "k_vertical_g4<etch>"
+                return "k_stencil<deposit>" if stencil else "k_vertical_g4<deposit>"
+            return "k_stencil<etch>" if stencil else "k_vertical_g4<etch>"
         kbytes = {}
         for q in range(args.steps):
             idx = (k + q) % len(flow)
@@ -217,13 +260,14 @@ def main():
         roofline = None
         # HBM traffic per launch from the PMC passes of the same command (tools/prof.sh), when committed
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-        if dom and os.path.exists(tpath) and args.n == 16384 and args.flow == "c4":
+        tpath = args.traffic or newest_traffic_file()
+        if dom and tpath and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if dom in tj.get("kernels", {}):
+            same_workload = tj.get("n") == args.n and tj.get("flow") == args.flow and tj.get("n_gpus", 1) == world
+            if same_workload and dom in tj.get("kernels", {}):
                 traffic = tj["kernels"][dom]["fetch_bytes_per_launch"] + tj["kernels"][dom]["write_bytes_per_launch"]
-                traffic_src = "profiles/r01_traffic.json"
+                traffic_src = {"file": os.path.relpath(tpath, ROOT), "git_blob": git_blob_hash(tpath)}
         if dom:
             achieved = cand[dom]["GBps"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -235,10 +279,13 @@ def main():
         out = {
             "metric": "column-updates/sec per process step", "value": round(cols / dt / 1e9, 4), "unit": "Gcol/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16 heights, f64/f32 arithmetic",
-            "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "u16 heights, f64/f32 arithmetic",
+            "data": "synthetic", "flow": args.flow, "n": args.n,
             "config": {"workload": f"{args.flow.upper()} flow ({len(flow)} process steps, 3 masks{', 128 cross-sections after every step' if slice_idx else ''}) on a {nxl}x{ny} column grid per GPU",
-                       "grid": [nxg, ny], "lmax": grid.Lmax, "parallelism": f"slab{world}"},
+                       "grid": [nxg, ny], "rows_per_gpu": nxl, "lmax": grid.Lmax, "parallelism": f"slab{world}",
+                       "world": dist.get_world_size() if world > 1 else 1},
+            "halo": {"bytes_sent_per_rank": halo_b, "bytes_per_step": round(halo_b / max(1, args.steps), 1),
+                     "exchange_ms_total": round(swap_s * 1e3, 3)},
             "whole_flow_algorithmic_GBps": round(total_alg * world / 1e9 / dt, 1),
             "checksum": "%016x" % check,
             "roofline": roofline, "kernels": kernels,

@@ -962,10 +962,24 @@ __device__ __forceinline__ RawGroup stream_load(const GridView& g, const uint8_t
     return o;
 }
 
+// What the host has verified for this handle and step, each a licence to replace double arithmetic
+// by float arithmetic with the same result:
+//   deq_f32    fmaf(q, zs_hi, q*zs_lo) == float32(double(q)*zscale) for every q < 65536 (checked one by one)
+//   skip_init  the step's thickness is a float32 number and equals the centre increment of the table: the
+//              start value float32(H + t) (cg1:499) is then the centre tap's candidate and need not be made
+//   grow_f32   zscale is large enough that two different float32 heights differ by more than the
+//              reference's 1e-9: "Hp - H > 1e-9" (cg1:537) is then "Hp > H" on the float32 values
+struct StreamOpts { float zs_hi, zs_lo, izf; int deq_f32, skip_init, grow_f32; };
+
+__device__ __forceinline__ float stream_deq(const GridView& g, const StreamOpts& o, unsigned q) {
+    if (o.deq_f32) { const float qf = (float)q; return __builtin_fmaf(qf, o.zs_hi, qf * o.zs_lo); }
+    return (float)((double)q * g.zs);
+}
+
 // float32(q*zscale) (cg1:465) of a raw group; left / right: the group lies beyond the first / last
 // column and repeats the edge column (cg1:374-380); not-etchable cells become +inf (cg1:718)
 template <bool ETCH>
-__device__ __forceinline__ float4 stream_heights(const GridView& g, const RawGroup& w, bool left, bool right, int matId, bool isAll) {
+__device__ __forceinline__ float4 stream_heights(const GridView& g, const StreamOpts& so, const RawGroup& w, bool left, bool right, int matId, bool isAll) {
     unsigned q[4], e = 0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -975,8 +989,7 @@ __device__ __forceinline__ float4 stream_heights(const GridView& g, const RawGro
     if (left) { q[1] = q[0]; q[2] = q[0]; q[3] = q[0]; }
     if (right) { q[0] = q[3]; q[1] = q[3]; q[2] = q[3]; }
     float4 h;
-    h.x = (float)((double)q[0] * g.zs); h.y = (float)((double)q[1] * g.zs);
-    h.z = (float)((double)q[2] * g.zs); h.w = (float)((double)q[3] * g.zs);
+    h.x = stream_deq(g, so, q[0]); h.y = stream_deq(g, so, q[1]); h.z = stream_deq(g, so, q[2]); h.w = stream_deq(g, so, q[3]);
     if (ETCH) {
         const float INF = __builtin_inff();
         if (left || right) e = 0;
@@ -999,7 +1012,7 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 template <int R, bool ETCH, bool MSG, bool MASKED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_stencil_stream(GridView g, const uint8_t* __restrict__ mask, int matId, double t, int Rimg,
                                                        const uint8_t* __restrict__ halo_lo, const uint8_t* __restrict__ halo_up,
-                                                       const float* __restrict__ quad, int* __restrict__ flags, unsigned long long* gstats) {
+                                                       const float* __restrict__ quad, const StreamOpts so, int* __restrict__ flags, unsigned long long* gstats) {
     using G = StreamGeom<R>;
     constexpr int Rp = G::Rp, PITCH = G::PITCH, W = G::W, HG = G::HG, TP = STREAM_TAB_PITCH;
     __shared__ __align__(16) float s_row[2][PITCH];
@@ -1040,8 +1053,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
     RawGroup in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R, Rimg, msg_n, m_jc, matId, halo_lo, halo_up), in_h;
     in_h.a = (u32x4)(0); in_h.m = 0;
     if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
-    *(float4*)(s_row[0] + Rp + 4 * lane) = stream_heights<ETCH>(g, in_m, false, m_right, matId, isAll);
-    if (has_halo) *(float4*)(s_row[0] + h_at) = stream_heights<ETCH>(g, in_h, h_left, h_right, matId, isAll);
+    *(float4*)(s_row[0] + Rp + 4 * lane) = stream_heights<ETCH>(g, so, in_m, false, m_right, matId, isAll);
+    if (has_halo) *(float4*)(s_row[0] + h_at) = stream_heights<ETCH>(g, so, in_h, h_left, h_right, matId, isAll);
     if (1 < rows_in) {
         in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + 1, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);
         if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + 1, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
@@ -1120,8 +1133,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
         // ---- stage input row r+1
         if (r + 1 < rows_in) {
             float* nxt = s_row[(r + 1) & 1];
-            *(float4*)(nxt + Rp + 4 * lane) = stream_heights<ETCH>(g, in_m, false, m_right, matId, isAll);
-            if (has_halo) *(float4*)(nxt + h_at) = stream_heights<ETCH>(g, in_h, h_left, h_right, matId, isAll);
+            *(float4*)(nxt + Rp + 4 * lane) = stream_heights<ETCH>(g, so, in_m, false, m_right, matId, isAll);
+            if (has_halo) *(float4*)(nxt + h_at) = stream_heights<ETCH>(g, so, in_h, h_left, h_right, matId, isAll);
         }
         // (the records loaded above are looked at from here on, not before the staging)
         if (ETCH && FIN) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
@@ -1132,38 +1145,90 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
             if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
         }
         // ---- the update of the output row
-        if (FIN) {
+        if (FIN && !ETCH) {
+            // _depoAtTop_ (cg1:397-426) by dz = Hp - H (cg1:534-540) on 4 columns, without double arithmetic
+            // where float arithmetic provably gives the same numbers (StreamOpts, and the quantiser below)
+            unsigned q[4]; float own[4], m[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) { q[c] = rec_z1(tv[c]); own[c] = stream_deq(g, so, q[c]); m[c] = A[0][c]; }
+            if (!so.skip_init) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) m[c] = CG_OP(m[c], (float)((double)own[c] + t));                 // cg1:499
+            }
+            unsigned grow = 0;                                  // columns with Hp - H > 1e-9 (cg1:537)
+            if (so.grow_f32) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) if (m[c] > own[c]) grow |= 1u << c;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++) if ((double)m[c] - (double)own[c] > CG_EPS) grow |= 1u << c;
+            }
+            grow &= act;
+            bool stored = false;
+            if (grow) {
+                // New top height: Math.round((q*zs + (Hp - H)) / zs) (cg1:407-411, 117-119).  In real numbers the
+                // argument is (Hp - e)/zs with e = H - q*zs, |e| <= 2^-24 q zs (H is the float32 of q*zs), and the
+                // double operations move it by < 1e-10.  y = Hp * float32(1/zs) is within 1.2e-7 y of Hp/zs.  So when y
+                // is farther than y*1.4e-7 + q*6.2e-8 + 2e-6 from a half-integer, the answer is the integer nearest y;
+                // the few columns where it is not take the literal double form.
+                unsigned qn[4], slow = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float y = m[c] * so.izf, rr = __builtin_rintf(y);
+                    const float margin = y * 1.4e-7f + (float)q[c] * 6.2e-8f + 2e-6f;
+                    qn[c] = (unsigned)(int)rr;
+                    if (!(__builtin_fabsf(y - rr) < 0.5f - margin) || !(y < 1.0e6f)) slow |= 1u << c;
+                }
+                slow &= grow;
+                if (slow) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        if ((slow >> c) & 1) qn[c] = quantz((double)q[c] * g.zs + ((double)m[c] - (double)own[c]), g.zs, g.inv_zs);
+                }
+                u32x4 nv = tv;
+                unsigned push = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (!((grow >> c) & 1)) continue;
+                    const uint32_t rc = tv[c];
+                    if (rc != 0 && rec_mat(rc) == matId) nv[c] = rec_with_z1(rc, qn[c]);
+                    else { nv[c] = rec_make_l(qn[c], matId, rc != 0 ? g.P : LNK_NONE); if (rc != 0) push |= 1u << c; }
+                }
+                if (push) {                                     // the old tops go into this step's plane as they are (see depo_group4)
+                    const size_t b = (size_t)g.P * g.N + c0;
+                    if (push == 15u) st_rec4(g.rec + b, tv);
+                    else {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) if ((push >> c) & 1) g.rec[b + c] = tv[c];
+                    }
+                }
+                st_rec4(g.top_w + c0, nv);
+                stored = true;
+            }
+            if (!stored && !m_right && g.top_w != g.top) st_rec4(g.top_w + c0, tv);          // columns that stay as they are
+        }
+        if (FIN && ETCH) {
             bool stored = false;
             if (act) {
                 float own[4], m[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    own[c] = (float)((double)rec_z1(tv[c]) * g.zs);
-                    const float init = ETCH ? (float)((double)own[c] - t) : (float)((double)own[c] + t);     // cg1:702 / cg1:499
+                    own[c] = stream_deq(g, so, rec_z1(tv[c]));
+                    const float init = (float)((double)own[c] - t);                                          // cg1:702
                     m[c] = CG_OP(A[0][c], init);
                 }
                 double dz[4] = {0, 0, 0, 0};
                 unsigned open = 0;
-                if (!ETCH) {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        if (!((act >> c) & 1)) continue;
-                        const double d = (double)m[c] - (double)own[c];          // cg1:534-537
-                        if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
-                    }
-                    if (open) stored = depo_group4<false>(g, c0, open, dz, matId, tv, loc[1], loc[2]);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        if (!((act >> c) & 1)) continue;
-                        float F = 0.f;                                           // floor = bottom of the top run of matId (cg1:646-660)
-                        if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, matId, tv[c], b4[c], loc[3]));
-                        const float hpv = fmaxf(0.f, fmaxf(F, m[c]));            // cg1:725
-                        const double d = (double)own[c] - (double)hpv;
-                        if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
-                    }
-                    if (open) stored = etch_group4<false>(g, c0, open, dz, matId, isAll, tv, act, b4, loc[1], loc[2]);
+                for (int c = 0; c < 4; c++) {
+                    if (!((act >> c) & 1)) continue;
+                    float F = 0.f;                                           // floor = bottom of the top run of matId (cg1:646-660)
+                    if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, matId, tv[c], b4[c], loc[3]));
+                    const float hpv = fmaxf(0.f, fmaxf(F, m[c]));            // cg1:725
+                    const double d = (double)own[c] - (double)hpv;
+                    if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
                 }
+                if (open) stored = etch_group4<false>(g, c0, open, dz, matId, isAll, tv, act, b4, loc[1], loc[2]);
             }
             if (!stored && !m_right && g.top_w != g.top) st_rec4(g.top_w + c0, tv);          // columns that stay as they are
         }

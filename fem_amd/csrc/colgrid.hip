@@ -117,6 +117,7 @@ struct cg_grid {
     Pending pend;
     std::map<int, Snapshot> snaps;
     // invariants tracked on the host
+    StreamOpts sopt = {};       // float-arithmetic licences of the streaming lateral kernel that depend on zscale alone (see StreamOpts)
     int len_bound = 0;          // upper bound of max(len); INT32_MAX = unknown
     bool has_gaps = false;      // some column may have a vertical gap between layers
     bool has_cavity = false;    // some column may hold a cavity layer (material 2)
@@ -693,12 +694,15 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
         const int n_int = stencil_bands(g->nx, ti, R, halo_lo != nullptr, halo_up != nullptr, PART_INTERIOR, bi);
         const int n_bnd = stencil_bands(g->nx, ti, R, halo_lo != nullptr, halo_up != nullptr, PART_BOUNDARY, bb);
         const int tiles_j = (g->ny + STRIP - 1) / STRIP;
+        StreamOpts sopt = g->sopt;
+        sopt.skip_init = (!etch && (double)(float)t_eff == t_eff && !K->quad.empty() && K->quad[0] == (float)t_eff) ? 1 : 0;
+        if (getenv("CG_STREAM_NOF32")) { sopt.deq_f32 = 0; sopt.skip_init = 0; sopt.grow_f32 = 0; }
 #define STREAM_L(RR, E, M, K_, BAND)                                                                           \
     do {                                                                                                       \
         gv.tile_i0 = (BAND).t0; gv.tile_in = (BAND).n; gv.sup_i = 1; gv.sup_j = 1;                             \
         const dim3 gridS((unsigned)(((long)(BAND).n * tiles_j + 7) / 8 * 8));                                  \
         hipLaunchKernelGGL((k_stencil_stream<RR, E, M, K_>), gridS, dim3(64), 0, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
-                           K->d_quad, g->d_flags, g->d_stats);                                                 \
+                           K->d_quad, sopt, g->d_flags, g->d_stats);                                           \
     } while (0)
 #define STREAM(RR, E, K_)                                                                                      \
     do {                                                                                                       \
@@ -963,6 +967,17 @@ int cg_create_slab(int nx_global, int ny, int i0, int nx_local, double dx, doubl
     g->N = (size_t)nx_local * ny; g->dx = dx; g->dy = dy; g->zscale = zscale;
     int lmax = next_pow2(lmax_init);
     if (lmax > 256) lmax = 256;
+    {   // what float arithmetic may stand in for double arithmetic at this zscale (StreamOpts)
+        StreamOpts& o = g->sopt;
+        o.zs_hi = (float)zscale; o.zs_lo = (float)(zscale - (double)o.zs_hi); o.izf = (float)(1.0 / zscale);
+        o.deq_f32 = 1;
+        for (unsigned q = 0; q < 65536u && o.deq_f32; q++) {
+            const float qf = (float)q;
+            if (std::fmaf(qf, o.zs_hi, qf * o.zs_lo) != (float)((double)q * zscale)) o.deq_f32 = 0;
+        }
+        o.grow_f32 = zscale >= 0.02 ? 1 : 0;               // 2^-24 * zscale > 1e-9 with room to spare
+        o.skip_init = 0;                                   // per step
+    }
     int rc = CG_OK;
     auto body = [&]() -> int {
         HIPCHK(g, hipStreamCreateWithFlags(&g->own_stream, hipStreamNonBlocking));

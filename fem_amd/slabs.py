@@ -21,6 +21,7 @@ fem_amd.ColumnGrid; the tests drive the same class with a CPU stand-in over the 
 """
 import contextlib
 import math
+import time
 
 import torch
 import torch.distributed as dist
@@ -93,6 +94,8 @@ class SlabGrid:
         self._rows = 0
         self._gaps_anywhere = None      # "some slab may hold a gap or a cavity": None = ask the ranks again
         self._mask_any = {}             # mask id -> "open somewhere in the domain" (all-reduced once per mask)
+        self.halo_bytes = 0             # bytes this rank has sent in halo exchanges of lateral steps
+        self.swap_seconds = 0.0         # host time between the start and the completion of those exchanges
         self.stream = None
         if self.device_side_comm():
             self.stream = stream if stream is not None else torch.cuda.Stream(self.device)
@@ -141,12 +144,16 @@ class SlabGrid:
         interior = getattr(self.grid, "stencil_interior", None)
         if not self.device_side_comm():
             self.grid.sync()                     # the rows are read by the host / by torch, not on the grid's stream
+        t0 = time.perf_counter()
         with self._on_stream():
             if interior is None or not hasattr(self.comm, "start_swap"):
-                return self.comm.swap(*bufs)
-            reqs = self.comm.start_swap(*bufs)
-            interior()
-            self.comm.finish_swap(reqs)
+                self.comm.swap(*bufs)
+            else:
+                reqs = self.comm.start_swap(*bufs)
+                interior()
+                self.comm.finish_swap(reqs)
+        self.swap_seconds += time.perf_counter() - t0
+        self.halo_bytes += n * (int(self.has_lower) + int(self.has_upper))
 
     def _step(self, kind, mask, mat, t, S):
         if self.world > 1:

@@ -68,6 +68,36 @@ def test_benchmark_flows_vs_oracle(flow_name, n):
     g.close()
 
 
+def test_bench_call_path_vs_oracle():
+    """The benchmark drives the grid through SlabGrid(world=1) -> cg_stencil_begin / cg_stencil_finish (not
+    cg_deposit_general) and re-creates the grid when the flow wraps: the same calls here, against the oracle."""
+    import fem_amd as fem
+    from fem_amd import flows
+    from fem_amd.slabs import SlabGrid
+    n = 1024
+    flow = flows.flow_c4()
+    specs = flows.mask_specs(2.0 * n)
+    g = fem.ColumnGrid(dx=2.0, dy=2.0, slab=(n, n, 0, n))
+    o = OracleGrid(2.0 * n, 2.0 * n, 2.0, 2.0)
+    gm, om = _masks(fem, flows, g, o, specs, sorted({s["mask"] for s in flow if s["mask"]}), n)
+    slab = SlabGrid(g, 0, 1, dx=2.0, dy=2.0, ny=n)
+    want = []
+    for s in flow:
+        flows.apply_step(o, s, om)
+        want.append(o.checksum())
+    for rep in range(2):                       # the second pass starts from createNewGrid on a used handle, as the bench's wrap does
+        slab.createNewGrid()
+        for k, s in enumerate(flow):
+            flows.apply_step(slab, s, gm)
+            assert slab.checksum() == want[k], f"pass {rep} step {k} {s}"
+    # without a look at the grid in between (the timed region never reads anything back)
+    slab.createNewGrid()
+    for s in flow:
+        flows.apply_step(slab, s, gm)
+    assert slab.checksum() == want[-1]
+    g.close()
+
+
 def test_full_size_properties():
     """16384 x 16384 (the benchmark size): no oracle, only properties that do not depend on size."""
     import fem_amd as fem

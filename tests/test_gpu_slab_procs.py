@@ -17,3 +17,26 @@ def test_two_processes_one_gpu():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert all(f"slab flow {n} ok on 2 ranks" in r.stdout for n in ("c4", "cs", "cwet", "cw"))
+
+
+@pytest.mark.gpu
+def test_bench_strong_scaling_rehearsal():
+    """bench.py --scaling strong with 2 ranks on one GPU (device tensors staged through gloo): the domain is the
+    one of the 1-rank run cut into two slabs, so the checksums must agree; the bench's own check of the timed
+    state runs in both."""
+    import json
+    root = os.path.dirname(HERE)
+    common = ["--size", "256", "--flow", "c4", "--steps", "20", "--warmup", "3", "--no-cpu"]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=240)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    a = json.loads(one.stdout.strip().splitlines()[-1])
+    env = dict(os.environ, BENCH_ONE_GPU="1", BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "2", "--scaling", "strong"] + common
+    two = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["scaling"] == "strong" and b["n_gpus"] == 2 and b["config"]["world"] == 2
+    assert b["config"]["grid"] == a["config"]["grid"] == [256, 256] and b["config"]["rows_per_gpu"] == 128
+    assert b["checksum"] == a["checksum"]
+    assert b["halo"]["bytes_sent_per_rank"] > 0 and a["halo"]["bytes_sent_per_rank"] == 0

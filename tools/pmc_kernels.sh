@@ -5,7 +5,7 @@ TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
-REPS=1 timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc -- python3 tools/step_times.py > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
+REPS=1 NOSTATS=1 timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc -- python3 tools/step_times.py > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/pmc/**/*counter_collection.csv", recursive=True)[0]

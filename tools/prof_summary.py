@@ -45,17 +45,25 @@ import json
 import re
 
 
-def label(k):
-    m = re.match(r"k_(stencil_sym|stencil_apply|vertical_g4|vertical_1)<(.*)>", k)
+def parse(k):
+    """-> (bench.py's group label, keeps statistics) of a step kernel, or None."""
+    m = re.match(r"k_(stencil_stream|stencil_sym|stencil_apply|vertical_g4|vertical_1)<(.*)>", k)
     if not m:
         return None
     args = [a.strip() for a in m.group(2).split(",")]
-    if m.group(1) == "stencil_sym":
-        etch = args[2]
-        return "k_stencil_sym<%s>" % ("etch" if etch == "true" else "deposit")
-    if m.group(1) == "stencil_apply":
-        return "k_stencil_sym<%s>" % ("etch" if args[0] == "true" else "deposit")
-    return "k_vertical_g4<%s>" % ("etch" if args[0] == "true" else "deposit")
+    kind = m.group(1)
+    if kind == "stencil_stream":          # <R, ETCH, MSG, MASKED>: never keeps statistics
+        return "k_stencil<%s>" % ("etch" if args[1] == "true" else "deposit"), False
+    if kind == "stencil_sym":             # <R, TJS, ETCH, STATS>
+        return "k_stencil<%s>" % ("etch" if args[2] == "true" else "deposit"), args[3] == "true"
+    if kind == "stencil_apply":           # <ETCH, STATS>
+        return "k_stencil<%s>" % ("etch" if args[0] == "true" else "deposit"), args[1] == "true"
+    return "k_vertical_g4<%s>" % ("etch" if args[0] == "true" else "deposit"), args[1] == "true"
+
+
+def label(k):
+    p = parse(k)
+    return p[0] if p else None
 
 
 # launch durations grouped the way bench.py groups them (its roofline.ms_avg is the average over the
@@ -64,14 +72,10 @@ grp = defaultdict(lambda: [0.0, 0])
 for f in find("trace/**/*kernel_stats.csv"):
     for row in csv.DictReader(open(f)):
         k = short(row["Name"])
-        lb = label(k)
-        m = re.match(r"k_(stencil_sym|vertical_g4)<(.*)>", k)
-        if not lb or not m:
+        pk = parse(k)
+        if not pk or pk[1]:
             continue
-        args = [a.strip() for a in m.group(2).split(",")]
-        stats = args[3] if m.group(1) == "stencil_sym" else args[1]
-        if stats == "true":
-            continue
+        lb = pk[0]
         grp[lb][0] += float(row["TotalDurationNs"]); grp[lb][1] += int(row["Calls"])
 if grp:
     print("== launch durations by bench.py's kernel groups (instances without statistics, warm-up + timed steps)")
@@ -80,13 +84,19 @@ if grp:
 
 tr = defaultdict(lambda: {"fetch_kb": 0.0, "write_kb": 0.0, "nf": 0, "nw": 0})
 for k in agg:
-    lb = label(k)
-    if not lb:
+    pk = parse(k)
+    if not pk or pk[1]:                   # the instances that keep statistics run in the untimed pass only
         continue
+    lb = pk[0]
     if "FETCH_SIZE" in agg[k]:
         tr[lb]["fetch_kb"] += agg[k]["FETCH_SIZE"]; tr[lb]["nf"] += cnt[k]["FETCH_SIZE"]
     if "WRITE_SIZE" in agg[k]:
         tr[lb]["write_kb"] += agg[k]["WRITE_SIZE"]; tr[lb]["nw"] += cnt[k]["WRITE_SIZE"]
+bench_line = {}
+for f in find("trace.log"):
+    for line in open(f):
+        if line.startswith("{") and '"metric"' in line:
+            bench_line = json.loads(line)
 res = {}
 for lb, v in tr.items():
     if v["nf"] and v["nw"]:
@@ -94,7 +104,8 @@ for lb, v in tr.items():
                    "launches_profiled": min(v["nf"], v["nw"])}
 if res:
     with open(os.path.join(out, "traffic.json"), "w") as f:
-        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python3 bench.py --no-cpu; counters are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B; checked on the vertical deposits, which read link (1 B) and top (4 B) per column: 1.342 GB expected at 16384^2, 0.671 GB-units reported)",
+        json.dump({"n": bench_line.get("n"), "flow": bench_line.get("flow"), "n_gpus": bench_line.get("n_gpus", 1),
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python3 bench.py --no-cpu; counters are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B; checked on the vertical deposits, which read the 4-byte top of every column: 1.074 GB expected at 16384^2)",
                    "kernels": res}, f, indent=1)
     print("== HBM traffic per launch (bytes)")
     for lb, v in sorted(res.items()):

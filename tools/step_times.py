@@ -19,14 +19,16 @@ for rep in range(REPS):
     g.createNewGrid(); g.sync()
     rows = []
     for k, s in enumerate(flow):
-        g.stats_enable(rep == 0)
+        g.stats_enable(rep == 0 and not os.environ.get("NOSTATS"))
         g.timer_start()
         flows.apply_step(g, s, masks)
         ms = g.timer_stop()
-        st = g.stats() if rep == 0 else None
+        st = g.stats() if (rep == 0 and not os.environ.get("NOSTATS")) else None
         rows.append((k, s, ms, st))
     if rep == 0:
         stats = [r[3] for r in rows]
+        if os.environ.get("NOSTATS"):
+            print("total %.2f ms | " % sum(r[2] for r in rows) + " ".join("%.2f" % r[2] for r in rows))
     elif os.environ.get("COMPACT"):
         v = [r[2] for r in rows]
         print("total %.2f ms | vdep %.2f vetch %.2f sdep %.2f setch %.2f | " % (
