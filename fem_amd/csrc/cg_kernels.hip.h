@@ -156,11 +156,70 @@ __device__ __forceinline__ void reload_top(const GridView& g, size_t c, int& l, 
     z0q = p2 != LNK_NONE ? rec_z1(g.rec[(size_t)p2 * g.N + c]) : 0u;
 }
 
+// The one-column primitives below also take a grid in whole form (interval k in plane k, the top
+// in plane len-1): the form the host keeps columns of more than LNK_NONE + 1 intervals in, which
+// the links of the split form cannot chain.  Slower (the planes an append or a cut touches depend
+// on the column length), and only reached by such stacks.
+
+// top record of column c of length l, either form
+__device__ __forceinline__ uint32_t top_record(const GridView& g, size_t c, int l) {
+    if (g.split) return g.top[c];
+    return l > 0 ? g.rec[(size_t)(l - 1) * g.N + c] : 0u;
+}
+
+// whole form: _depoAtTop_
+__device__ __forceinline__ int depo_at_top_whole(const GridView& g, size_t c, int l, int matId, double dz) {
+    const uint32_t r = l > 0 ? g.rec[(size_t)(l - 1) * g.N + c] : 0;
+    const uint16_t q = quantz((double)rec_z1(r) * g.zs + dz, g.zs, g.inv_zs);
+    if (l > 0 && rec_mat(r) == matId) { g.rec[(size_t)(l - 1) * g.N + c] = rec_with_z1(r, q); return 1; }
+    if (l >= g.lmax) return 3;
+    g.rec[(size_t)l * g.N + c] = rec_make(q, matId);
+    g.len[c] = (uint8_t)(l + 1);
+    return 2;
+}
+
+// whole form: _applyEtchAt; removed slots are cleared, a gap uncovered by a removal goes with it
+__device__ __forceinline__ int apply_etch_at_whole(const GridView& g, size_t c, int l, int matId, double dz, bool isAll) {
+    double remaining = dz;
+    int removed = 0; bool touched = false;
+    const int l0 = l;
+    while (remaining > CG_EPS && l > 0) {
+        const size_t at = (size_t)(l - 1) * g.N + c;
+        const uint32_t r = g.rec[at];
+        if (!isAll && rec_mat(r) != matId) break;
+        const unsigned z0q = l > 1 ? rec_z1(g.rec[(size_t)(l - 2) * g.N + c]) : 0u;
+        const double z1 = (double)rec_z1(r) * g.zs, z0 = (double)z0q * g.zs, thick = z1 - z0;
+        touched = true;
+        if (remaining < thick - CG_EPS) { g.rec[at] = rec_with_z1(r, quantz(z1 - remaining, g.zs, g.inv_zs)); break; }
+        remaining -= thick; removed++;
+        g.rec[at] = 0; l--;
+        if (l > 0 && rec_hole(g.rec[(size_t)(l - 1) * g.N + c])) { g.rec[(size_t)(l - 1) * g.N + c] = 0; l--; }
+    }
+    if (l != l0) g.len[c] = (uint8_t)l;
+    return (touched ? 0x10000 : 0) | removed;
+}
+
+// whole form: bottom of the top run of matId (the top layer, interval l-1, is known to be matId)
+__device__ __forceinline__ double floor_of_top_run_whole(const GridView& g, size_t c, int l, int matId, unsigned& scanned) {
+    scanned++;
+    int k = l - 2;                 // topmost interval not known to belong to the run
+    while (k >= 0) {
+        const uint32_t b = g.rec[(size_t)k * g.N + c];
+        int kl = k;                // the layer to compare with: interval k, or what lies under the gap k
+        if (rec_hole(b)) { kl = k - 1; if (kl < 0) break; }
+        if (rec_mat(g.rec[(size_t)kl * g.N + c]) != matId) break;
+        scanned++;
+        k = kl - 1;
+    }
+    return k >= 0 ? (double)rec_z1(g.rec[(size_t)k * g.N + c]) * g.zs : 0.0;
+}
+
 // _depoAtTop_ (script_columngrid.js:397-426) for one column.  `l` is the column's current
 // length.  Returns 0 = nothing, 1 = top layer extended, 2 = layer appended, 3 = append needed
 // but no plane left (column untouched; the host grows the planes and re-runs those columns).
 __device__ __forceinline__ int depo_at_top(const GridView& g, size_t c, int l, int matId, double dz) {
     if (!(dz > 0)) return 0;
+    if (!g.split) return depo_at_top_whole(g, c, l, matId, dz);
     const uint32_t r = l > 0 ? g.top[c] : 0;
     const uint32_t topq = rec_z1(r);
     const uint16_t q = quantz((double)topq * g.zs + dz, g.zs, g.inv_zs);
@@ -190,6 +249,7 @@ __device__ __forceinline__ int etch_round(const GridView& g, uint32_t& r, unsign
 // low 16 bits and 0x10000 if the column was touched at all.
 __device__ __forceinline__ int apply_etch_at(const GridView& g, size_t c, int l, int matId, double dz, bool isAll) {
     if (!(dz > 0) || l <= 0) return 0;
+    if (!g.split) return apply_etch_at_whole(g, c, l, matId, dz, isAll);
     double remaining = dz;
     int removed = 0; bool touched = false;
     const int l0 = l;
@@ -265,7 +325,7 @@ __global__ __launch_bounds__(256) void k_vertical_1(GridView g, const uint8_t* _
         } else {
             if (only_len >= 0) {
                 if (l != only_len) continue;
-                if (l > 0 && rec_mat(g.top_w[c]) == matId) continue;     // done in the first pass
+                if (l > 0 && rec_mat(g.split ? g.top_w[c] : top_record(g, c, l)) == matId) continue;     // done in the first pass
             }
             const int r = depo_at_top(g, c, l, matId, t);
             if (r == 3) flags[0] = 1;
@@ -607,7 +667,7 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 const uint32_t rr = g.top[c];
                 float h = (float)((double)rec_z1(rr) * g.zs);
                 own[r] = h;
-                if (only_len < 0 && g.top_w != g.top) g.top_w[c] = rr;    // columns that stay as they are
+                if (g.split && only_len < 0 && g.top_w != g.top) g.top_w[c] = rr;    // columns that stay as they are
                 if (ETCH) {
                     act[r] = (!mask || mask[c]) && etchable(rr, matId, isAll);
                     m[r] = (float)((double)h - t);                     // cg1:702
@@ -651,9 +711,11 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 if (ETCH) {
                     float F = 0.f;
                     if (!isAll && l > 0) {
-                        const uint32_t rt = g.top[c];
-                        const uint32_t below = rec_lnk(rt) != LNK_NONE ? g.rec[(size_t)rec_lnk(rt) * g.N + c] : 0u;
-                        F = (float)fmax(0.0, floor_of_top_run(g, c, matId, rt, below, loc[3]));
+                        if (g.split) {
+                            const uint32_t rt = g.top[c];
+                            const uint32_t below = rec_lnk(rt) != LNK_NONE ? g.rec[(size_t)rec_lnk(rt) * g.N + c] : 0u;
+                            F = (float)fmax(0.0, floor_of_top_run(g, c, matId, rt, below, loc[3]));
+                        } else F = (float)fmax(0.0, floor_of_top_run_whole(g, c, l, matId, loc[3]));
                     }
                     float hp = fmaxf(0.f, fmaxf(F, m[r]));             // cg1:725
                     double dz = (double)own[r] - (double)hp;
@@ -665,7 +727,7 @@ __global__ __launch_bounds__(256) void k_stencil_apply(GridView g, const uint8_t
                 } else {
                     if (only_len >= 0) {
                         if (l != only_len) continue;
-                        if (l > 0 && rec_mat(g.top_w[c]) == matId) continue;     // done in the first pass
+                        if (l > 0 && rec_mat(g.split ? g.top_w[c] : top_record(g, c, l)) == matId) continue;     // done in the first pass
                     }
                     double dz = (double)m[r] - (double)own[r];         // cg1:534-536
                     if (STATS) loc[0]++;
@@ -1372,6 +1434,16 @@ __global__ __launch_bounds__(256) void k_max_top_split(GridView g, unsigned* __r
     }
     for (int o = 32; o > 0; o >>= 1) { unsigned a = __shfl_down(mq, o, 64); mq = a > mq ? a : mq; }
     if ((threadIdx.x & 63) == 0) lazy_umax(&out[0], mq);
+}
+
+// whole form: top[c] = the column's top interval (0: empty), so that a lateral step can stage the OLD
+// heights from the top stream while it rewrites the planes in place
+__global__ __launch_bounds__(256) void k_snapshot_tops(GridView g) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+        const int l = g.len[c];
+        g.top[c] = l > 0 ? (g.rec[(size_t)(l - 1) * g.N + c] & REC_BODY & ~REC_MARK) : 0u;
+    }
 }
 
 // split form: len[c] recounted from the chain (the 4-columns-per-thread kernels do not maintain it)

@@ -361,8 +361,7 @@ int ensure_len(cg_grid* g) {
 int ensure_split(cg_grid* g) {
     if (g->split) return CG_OK;
     if (g->len_bound > std::min(g->lmax, SPLIT_PLANES + 1)) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; }
-    if (g->len_bound > SPLIT_PLANES + 1)
-        return fail(g, CG_ERR_UNSUPPORTED, "a column holds %d intervals, the vertical and lateral steps take at most %d", g->len_bound, SPLIT_PLANES + 1);
+    if (g->len_bound > SPLIT_PLANES + 1) return CG_OK;        // too tall for the links: the steps run on the whole form (see run_deep_*)
     ProfScope ps(g, CG_K_OTHER);
     hipLaunchKernelGGL(k_promote, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g));
     HIPCHK(g, hipGetLastError());
@@ -594,9 +593,12 @@ int take_append_plane(cg_grid* g, int* P) {
             int rc = ensure_whole(g); if (rc) return rc;
             rc = refresh_len_bound(g, nullptr); if (rc) return rc;
             rc = ensure_split(g); if (rc) return rc;
+            if (!g->split) { *P = -1; return CG_OK; }                             // a column is too tall for the links: the caller runs on the whole form
             if (g->nextp >= usable() && g->lmax < SPLIT_PLANES) { rc = grow_planes(g); if (rc) return rc; }      // the columns need them, budget or not
-            if (g->nextp >= usable())
-                return fail(g, CG_ERR_UNSUPPORTED, "a column holds more than %d intervals", SPLIT_PLANES);
+            if (g->nextp >= usable()) {                                          // max(len) - 1 == SPLIT_PLANES: as tall as the links reach, nothing to append into
+                rc = ensure_whole(g); if (rc) return rc;
+                *P = -1; return CG_OK;
+            }
         }
     }
     *P = g->nextp++;
@@ -606,13 +608,13 @@ int take_append_plane(cg_grid* g, int* P) {
 // vertical deposit: the 4-column kernel while every column has a plane to spare, otherwise the
 // one-column kernel with the growth protocol of the reference (an append that finds no room)
 int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
-    int P = 0;
-    { int rcp = take_append_plane(g, &P); if (rcp) return rcp; }
+    int P = -1;
+    if (g->split) { int rcp = take_append_plane(g, &P); if (rcp) return rcp; }      // (may find a column too tall and leave the grid whole)
     bool may_overflow = g->len_bound >= g->lmax;
     if (may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; may_overflow = g->len_bound >= g->lmax; }
     const dim3 grid(blocks_for(g->N)), blk(256);
     GridView gv = view(g); gv.P = P;
-    if (g->N % 4 == 0 && !may_overflow) {        // 4 columns per thread, no look at the lengths
+    if (g->split && g->N % 4 == 0 && !may_overflow) {        // 4 columns per thread, no look at the lengths
         ProfScope ps(g, CG_K_DEPO_VERTICAL);
         launch_vertical<false>(g, mask, mat, t, P);
         HIPCHK(g, hipGetLastError());
@@ -676,10 +678,10 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
                    const uint8_t* halo_lo, const uint8_t* halo_up, int P, int part = PART_ALL, bool keep_len = false) {
     // keep_len: a column may be full, so the lengths matter -> the general kernel, which reads and
     // maintains them; otherwise the symmetric kernel where it applies, which leaves them behind
-    const bool sym = only_len < 0 && !keep_len && K->sym_ok && g->ny % 4 == 0 && !getenv("CG_NO_SYM");
+    const bool sym = g->split && only_len < 0 && !keep_len && K->sym_ok && g->ny % 4 == 0 && !getenv("CG_NO_SYM");
     if (!sym) { int rcl = ensure_len(g); if (rcl) return rcl; }
     GridView gv = view(g);
-    gv.top_w = g->top_alt; gv.P = P;
+    gv.top_w = g->split ? g->top_alt : g->top; gv.P = P;      // (whole form: the planes are rewritten in place, top is only the copy of the old tops)
     const size_t lds = stencil_lds_bytes(R);
     const dim3 blk(256);
     Band bands[2];
@@ -1302,7 +1304,7 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     if (latRange < std::min(g->dx, g->dy)) {                              // cg1:445, 609
         if (kind == CG_STENCIL_DEPOSIT) return run_depo_vertical(g, mask, mat, t);
         const dim3 grid(blocks_for(g->N)), blk(256);
-        if (g->N % 4 == 0) {    // 4 columns per thread, no look at the lengths
+        if (g->split && g->N % 4 == 0) {    // 4 columns per thread, no look at the lengths
             ProfScope ps(g, CG_K_ETCH_VERTICAL);
             launch_vertical<true>(g, mask, mat, t, -1);
             g->len_valid = false;
@@ -1333,6 +1335,13 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
         return fail(g, CG_ERR_UNSUPPORTED, "slab of %d rows is thinner than the stencil radius %d", g->nx, R);
     int rc = ensure_stencil_scratch(g, R, has_lower || has_upper); if (rc) return rc;
     rc = upload_taps(g, K, R); if (rc) return rc;
+    if (!g->split) {
+        // columns too tall for the split form: the step rewrites the planes in place and reads the OLD heights
+        // from a copy of the tops made now
+        ProfScope ps(g, CG_K_OTHER);
+        hipLaunchKernelGGL(k_snapshot_tops, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g));
+        HIPCHK(g, hipGetLastError());
+    }
     if (has_lower || has_upper) {
         ProfScope ps(g, CG_K_HALO);
         hipLaunchKernelGGL(k_halo_pack, dim3(blocks_for((size_t)R * g->ny)), dim3(256), 0, g->stream, view(g), mask, mat,
@@ -1381,7 +1390,20 @@ static int stencil_prepare_deposit(cg_grid* g) {
     p.may_overflow = g->len_bound >= g->lmax;
     if (p.may_overflow) { int rc = refresh_len_bound(g, nullptr); if (rc) return rc; p.may_overflow = g->len_bound >= g->lmax; }
     if (p.may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
-    return take_append_plane(g, &p.P);
+    p.P = -1;
+    if (!g->split) return CG_OK;                           // whole form: appends go to plane len
+    const bool was_split = g->split;
+    int rc = take_append_plane(g, &p.P); if (rc) return rc;
+    if (was_split && !g->split) {
+        // the compaction found a column as tall as the links reach: the step runs on the whole form, whose old
+        // heights come from a copy of the tops (the halo rows packed in cg_stencil_begin hold the same heights)
+        ProfScope ps(g, CG_K_OTHER);
+        hipLaunchKernelGGL(k_snapshot_tops, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g));
+        HIPCHK(g, hipGetLastError());
+        p.may_overflow = g->len_bound >= g->lmax;
+        if (p.may_overflow) HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
+    }
+    return CG_OK;
 }
 
 int cg_stencil_interior(cg_grid* g) {
@@ -1416,7 +1438,7 @@ int cg_stencil_finish(cg_grid* g) {
     const int part = p.interior_done ? PART_BOUNDARY : PART_ALL;
     if (etch) {
         int rc = launch_stencil(g, true, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, -1, part); if (rc) return rc;
-        std::swap(g->top, g->top_alt);
+        if (g->split) std::swap(g->top, g->top_alt);
         return CG_OK;
     }
 
@@ -1429,7 +1451,7 @@ int cg_stencil_finish(cg_grid* g) {
             rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, oldL, halo_lo, halo_up, p.P); if (rc) return rc;
         }
     }
-    std::swap(g->top, g->top_alt);
+    if (g->split) std::swap(g->top, g->top_alt);
     if (g->len_bound < 255) g->len_bound += 1;
     rc = sync_vis(g); if (rc) return rc;
     // identify_cavity (cg1:543) -- a no-op while no column has a vertical gap.  On a slab the

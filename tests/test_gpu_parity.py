@@ -537,6 +537,43 @@ def test_many_deposit_steps_recycle_planes(budget):
     g.close()
 
 
+def test_columns_taller_than_64_intervals():
+    """Stacks deeper than the split form's links reach (64 intervals): the engine keeps such a grid in whole form
+    and runs vertical and lateral steps, growth of Lmax included, through the one-column kernels; when etches
+    bring the stacks down again it returns to the split form.  Every step against the oracle."""
+    fem = _engine()
+    nx, ny = 40, 36
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    rng = _lcg(77)
+    red = fem.reduce_mask(_random_mask_data(rng, 2 * nx, 6))
+    gm, om = g.mask_from_shapes(red), o.mask_raster(red)
+    def both(fn, *a):
+        getattr(g, fn)(*[gm if x is om else x for x in a]); getattr(o, fn)(*a)
+    for k in range(100):
+        mask = om if k % 5 == 3 else None
+        S = 1.0 if k % 7 == 6 else 0.0                     # now and then a conformal deposit (R = 1)
+        both("deposit_general", mask, 3 + k % 2, 1.0 + 0.1 * (k % 4) + (1.2 if S else 0), S)
+        assert g.checksum() == o.checksum(), f"deposit {k}"
+        assert g.Lmax == o.Lmax, f"deposit {k}"
+        if k % 9 == 8:
+            both("etch_general", om, 255, 0.7, 0.0 if k % 2 else 1.0)   # partial cuts, vertical and lateral (t*S = 0.7 < dx: vertical either way)
+            assert g.checksum() == o.checksum(), f"etch {k}"
+        if k == 80:
+            both("etch_general", None, 3 + k % 2, 2.5, 1.0)            # a lateral etch (R = 2) on the tall stacks
+            assert g.checksum() == o.checksum(), f"lateral etch {k}"
+    assert o.arrays()[0].max() > 70 and g.Lmax == o.Lmax >= 80
+    _assert_same(g, o.arrays(), "tall stacks")
+    # down again: whole layers go, the stacks fit the links again, and the fast kernels take over
+    both("etch_general", None, 255, 60.0, 0.0)
+    assert g.checksum() == o.checksum()
+    for k in range(6):
+        both("deposit_general", None if k % 2 else om, 5 + k % 2, 2.0, 1.0 if k == 3 else 0.0)
+        assert g.checksum() == o.checksum(), f"after the etch, deposit {k}"
+    _assert_same(g, o.arrays(), "after coming down")
+    g.close()
+
+
 @pytest.mark.parametrize("dx,zs,lmax", [(1.0, 0.1, 32), (2.0, 0.05, 32), (3.0, 0.25, 16), (0.5, 0.2, 32), (2.0, 0.1, 4), (2.0, 0.1, 1)])
 def test_other_pitches_and_height_steps(dx, zs, lmax):
     """Cell pitch and height quantum other than the defaults (2 nm, 0.1 nm), small initial Lmax
