@@ -434,11 +434,10 @@ __device__ __forceinline__ void load_below4_flat(const GridView& g, size_t c0, c
 // tv = the 4 tops; `have` names the columns whose interval below the top the caller has loaded
 // already (b0, see load_below4).  A column that loses its whole top layer continues with the
 // interval below it.
+// Register form: r[] holds the 4 tops on entry and the new tops on return; returns the columns touched.
 template <bool STATS>
-__device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsigned open, const double (&dz)[4], int matId,
-                                            bool isAll, u32x4 tv, unsigned have, const uint32_t (&b0)[4],
-                                            unsigned& n_touched, unsigned& n_removed) {
-    uint32_t r[4] = {tv[0], tv[1], tv[2], tv[3]};
+__device__ __forceinline__ unsigned etch_group4_regs(const GridView& g, size_t c0, unsigned open, const double (&dz)[4], int matId,
+                                                     bool isAll, uint32_t (&r)[4], unsigned have, const uint32_t (&b0)[4], unsigned& n_removed) {
     double rem[4] = {dz[0], dz[1], dz[2], dz[3]};
     uint32_t b[4] = {b0[0], b0[1], b0[2], b0[3]};
     unsigned dirty = 0, act = 0;
@@ -468,6 +467,15 @@ __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsign
         }
         act = next;
     }
+    return dirty;
+}
+
+template <bool STATS>
+__device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsigned open, const double (&dz)[4], int matId,
+                                            bool isAll, u32x4 tv, unsigned have, const uint32_t (&b0)[4],
+                                            unsigned& n_touched, unsigned& n_removed) {
+    uint32_t r[4] = {tv[0], tv[1], tv[2], tv[3]};
+    const unsigned dirty = etch_group4_regs<STATS>(g, c0, open, dz, matId, isAll, r, have, b0, n_removed);
     if (dirty) {
         u32x4 nv; nv[0] = r[0]; nv[1] = r[1]; nv[2] = r[2]; nv[3] = r[3];
         st_rec4(g.top_w + c0, nv);
@@ -1270,29 +1278,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
             if (!stored && !m_right && g.top_w != g.top) st_rec4(g.top_w + c0, tv);          // columns that stay as they are
         }
         if (FIN && ETCH) {
-            bool stored = false;
-            if (act) {
-                float own[4], m[4];
+            // _applyEtchAt (cg1:553-589) by dz = H - Hp (cg1:730-739) on 4 columns.  The usual outcomes -- a cut inside the
+            // top layer, or the top layer going as a whole with nothing more to take below -- are decided here, in float
+            // arithmetic where that provably gives the reference's numbers and otherwise by the reference's own double
+            // expressions; a column that goes on into further layers, rests on a gap, or whose floor lies below the
+            // layer under it takes the general form (etch_group4_regs).
+            uint32_t rn[4] = {tv[0], tv[1], tv[2], tv[3]};
+            double dzs[4] = {0, 0, 0, 0};
+            unsigned walk = 0, general = 0, changed = 0;
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    own[c] = stream_deq(g, so, rec_z1(tv[c]));
-                    const float init = (float)((double)own[c] - t);                                          // cg1:702
-                    m[c] = CG_OP(A[0][c], init);
+            for (int c = 0; c < 4; c++) {
+                if (!((act >> c) & 1)) continue;
+                const uint32_t rc = tv[c], b = b4[c];
+                const bool has_b = rec_lnk(rc) != LNK_NONE;
+                const unsigned q1 = rec_z1(rc), bq = has_b ? rec_z1(b) : 0u;
+                if (has_b && (rec_hole(b) || (!isAll && rec_mat(b) == matId))) { walk |= 1u << c; continue; }     // floor and cut need a look further down
+                const float own = stream_deq(g, so, q1), bottom = stream_deq(g, so, bq);
+                float m = A[0][c];
+                if (!so.skip_init) m = CG_OP(m, (float)((double)own - t));                                       // cg1:702
+                const float hpv = fmaxf(0.f, fmaxf(isAll ? 0.f : bottom, m));                                    // cg1:725 (the floor is the layer's own bottom)
+                const bool cut = so.grow_f32 ? own > hpv : (double)own - (double)hpv > CG_EPS;                    // cg1:731-733
+                if (!cut) continue;
+                // cg1:574: the cut stays inside the top layer iff remaining < thick - 1e-9, remaining = H - Hp, thick = z1 - z0.
+                // H and `bottom` are the float32 of z1 and z0 (off by <= 2^-24 of them), so remaining - thick = -(Hp - bottom) + e,
+                // |e| < 6e-8 (H + bottom): a gap of twice that and 1e-8 decides it; closer calls use the double expressions.
+                bool partial = (hpv - bottom) > ((own + bottom) * 1.3e-7f + 1.0e-8f) * 1.01f;
+                double rem = 0;
+                if (!partial) {
+                    rem = (double)own - (double)hpv;
+                    const double thick = (double)q1 * g.zs - (double)bq * g.zs;
+                    partial = rem < thick - CG_EPS;
+                    if (!partial) {                                                                               // the layer goes (cg1:579-587)
+                        const double rest = rem - thick;
+                        if (has_b && rest > CG_EPS && (isAll || rec_mat(b) == matId)) { dzs[c] = rem; general |= 1u << c; continue; }
+                        rn[c] = has_b ? b : 0u; changed |= 1u << c;
+                        continue;
+                    }
                 }
-                double dz[4] = {0, 0, 0, 0};
-                unsigned open = 0;
+                // new top of the cut layer: Math.round((z1 - remaining)/zs) = round((Hp - e1)/zs), as in the deposit update
+                const float y = hpv * so.izf, rr = __builtin_rintf(y);
+                unsigned qn = (unsigned)(int)rr;
+                if (!(__builtin_fabsf(y - rr) < 0.5f - (y * 1.4e-7f + (float)q1 * 6.2e-8f + 2e-6f)) || !(y < 1.0e6f))
+                    qn = quantz((double)q1 * g.zs - ((double)own - (double)hpv), g.zs, g.inv_zs);
+                rn[c] = rec_with_z1(rc, qn); changed |= 1u << c;
+            }
+            if (walk) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    if (!((act >> c) & 1)) continue;
+                    if (!((walk >> c) & 1)) continue;
+                    const float own = stream_deq(g, so, rec_z1(tv[c]));
+                    const float m = CG_OP(A[0][c], (float)((double)own - t));
                     float F = 0.f;                                           // floor = bottom of the top run of matId (cg1:646-660)
                     if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, matId, tv[c], b4[c], loc[3]));
-                    const float hpv = fmaxf(0.f, fmaxf(F, m[c]));            // cg1:725
-                    const double d = (double)own[c] - (double)hpv;
-                    if (d > CG_EPS) { dz[c] = d; open |= 1u << c; }
+                    const float hpv = fmaxf(0.f, fmaxf(F, m));
+                    const double d = (double)own - (double)hpv;
+                    if (d > CG_EPS) { dzs[c] = d; general |= 1u << c; }
                 }
-                if (open) stored = etch_group4<false>(g, c0, open, dz, matId, isAll, tv, act, b4, loc[1], loc[2]);
             }
-            if (!stored && !m_right && g.top_w != g.top) st_rec4(g.top_w + c0, tv);          // columns that stay as they are
+            if (general) changed |= etch_group4_regs<false>(g, c0, general, dzs, matId, isAll, rn, act, b4, loc[2]);
+            if (!m_right && (changed || g.top_w != g.top)) {
+                u32x4 nv; nv[0] = rn[0]; nv[1] = rn[1]; nv[2] = rn[2]; nv[3] = rn[3];
+                st_rec4(g.top_w + c0, nv);
+            }
         }
         if (ETCH && FIN && r + 2 < rows_in) {
             in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);

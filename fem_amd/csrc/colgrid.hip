@@ -697,7 +697,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
         const int n_bnd = stencil_bands(g->nx, ti, R, halo_lo != nullptr, halo_up != nullptr, PART_BOUNDARY, bb);
         const int tiles_j = (g->ny + STRIP - 1) / STRIP;
         StreamOpts sopt = g->sopt;
-        sopt.skip_init = (!etch && (double)(float)t_eff == t_eff && !K->quad.empty() && K->quad[0] == (float)t_eff) ? 1 : 0;
+        sopt.skip_init = ((double)(float)t_eff == t_eff && !K->quad.empty() && K->quad[0] == (float)t_eff) ? 1 : 0;
         if (getenv("CG_STREAM_NOF32")) { sopt.deq_f32 = 0; sopt.skip_init = 0; sopt.grow_f32 = 0; }
 #define STREAM_L(RR, E, M, K_, BAND)                                                                           \
     do {                                                                                                       \
