@@ -54,10 +54,10 @@ def build_masks(fem, flows, grid, specs, names, nx, ny, i0, LX, LY, device):
     for name in names:
         spec = specs[name]
         if spec["kind"] == "shapes":
-            out[name] = grid.mask_from_shapes(fem.reduce_mask(spec["data"]))
+            out[name] = grid.mask_from_shapes(fem.reduce_mask(spec["data"], packed=True))
             continue
         data = flows.shapes_of(spec, LX, LY, x_range=(2.0 * i0, 2.0 * (i0 + nx)))
-        out[name] = grid.mask_from_shapes(fem.reduce_mask(data))
+        out[name] = grid.mask_from_shapes(fem.reduce_mask(data, packed=True))
         del data
         want = flows.raster_torch(spec, nx, ny, i0, device)
         got = torch.from_numpy(out[name].download()).to(device)

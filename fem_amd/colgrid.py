@@ -9,6 +9,7 @@ mask is a device raster built once per mask (`Mask`), `None` meaning "no mask".
 There is no CPU fallback: if the HIP library cannot be loaded every constructor raises.
 """
 import ctypes as C
+import array
 import math
 import os
 
@@ -169,16 +170,27 @@ def load_library(path=None):
     return lib
 
 
-def reduce_mask(mask_data):
+SHAPE_DTYPE = np.dtype([("type", "<i4"), ("positive", "<i4"), ("rotated", "<i4"), ("pt_off", "<i4"), ("pt_cnt", "<i4"), ("_pad", "<i4"),
+                        ("left", "<f8"), ("top", "<f8"), ("w", "<f8"), ("h", "<f8"), ("cosr", "<f8"), ("sinr", "<f8"),
+                        ("scale_x", "<f8"), ("scale_y", "<f8"), ("a", "<f8"), ("b", "<f8")])      # = CgShape, field for field
+_SHAPE_FIELDS = [n for n in SHAPE_DTYPE.names if n != "_pad"]
+assert SHAPE_DTYPE.itemsize == C.sizeof(CgShape)
+
+
+def reduce_mask(mask_data, packed=False):
     """Python twin of fem_amd/js/maskshapes.js: fabric JSON -> {'open', 'shapes', 'pts'}.
 
     Follows template/script_runtime.js:54-129 of the reference.  cos/sin come from this
     process's libm; a JavaScript host passes its own values instead.
+    packed=True: 'shapes' is a numpy record array laid out as cg_shape (what mask_from_shapes hands to
+    the library as it is: masks of 10^5 shapes and more then cost no second pass over Python objects).
     """
     if not mask_data or not mask_data.get("objects"):
         if not mask_data or "objects" not in mask_data or mask_data["objects"] is None:
-            return {"open": True, "shapes": [], "pts": []}
+            return {"open": True, "shapes": np.zeros(0, SHAPE_DTYPE) if packed else [], "pts": []}
     shapes, pts = [], []
+    flat = array.array("d")
+    add = flat.extend if packed else None
     for obj in mask_data["objects"]:
         if not obj.get("visible"):
             continue
@@ -212,19 +224,35 @@ def reduce_mask(mask_data):
             for p in obj["path"]:
                 if p[0] in ("L", "M"):
                     pts += [p[1], p[2]]; cnt += 1
-        shapes.append([typ, positive, rotated, off, cnt, left, top, w, h, cosr, sinr, sx, sy, a, b])
+        if packed:
+            try:
+                add((typ, positive, rotated, off, cnt, left, top, w, h, cosr, sinr, sx, sy, a, b))
+            except TypeError:                 # numbers given as text and the like
+                del flat[15 * (len(flat) // 15):]
+                add([float(v) for v in (typ, positive, rotated, off, cnt, left, top, w, h, cosr, sinr, sx, sy, a, b)])
+        else:
+            shapes.append([typ, positive, rotated, off, cnt, left, top, w, h, cosr, sinr, sx, sy, a, b])
+    if packed:
+        shapes = _records(np.frombuffer(flat, dtype=np.float64).reshape(-1, 15))
     return {"open": False, "shapes": shapes, "pts": pts}
 
 
+def _records(table):
+    """(n, 15) numbers in the order of a reduced shape -> n records of SHAPE_DTYPE."""
+    rec = np.zeros(table.shape[0], SHAPE_DTYPE)
+    for k, name in enumerate(_SHAPE_FIELDS):
+        rec[name] = table[:, k]
+    return rec
+
+
 def _pack_shapes(reduced):
-    n = len(reduced["shapes"])
-    arr = (CgShape * max(1, n))()
-    for s, r in enumerate(reduced["shapes"]):
-        arr[s].type, arr[s].positive, arr[s].rotated, arr[s].pt_off, arr[s].pt_cnt = [int(v) for v in r[:5]]
-        (arr[s].left, arr[s].top, arr[s].w, arr[s].h, arr[s].cosr, arr[s].sinr,
-         arr[s].scale_x, arr[s].scale_y, arr[s].a, arr[s].b) = [float(v) for v in r[5:15]]
+    """-> (record array kept alive by the caller, number of shapes, points as float64)."""
+    sh = reduced["shapes"]
+    if not (isinstance(sh, np.ndarray) and sh.dtype == SHAPE_DTYPE):
+        sh = _records(np.asarray(sh, dtype=np.float64).reshape(-1, 15))
+    sh = np.ascontiguousarray(sh)
     pts = np.ascontiguousarray(reduced["pts"], dtype=np.float64)
-    return arr, n, pts
+    return sh, int(sh.shape[0]), pts
 
 
 class Mask:
@@ -329,7 +357,7 @@ class ColumnGrid:
         """reduced: output of reduce_mask() / maskshapes.js reduceMask()."""
         arr, n, pts = _pack_shapes(reduced)
         mid = C.c_int()
-        self._chk(self.lib.cg_mask_from_shapes(self.h, C.cast(arr, C.c_void_p), n,
+        self._chk(self.lib.cg_mask_from_shapes(self.h, arr.ctypes.data if n else None, n,
                                                pts.ctypes.data if pts.size else None, pts.size // 2, C.byref(mid)))
         return Mask(self, mid.value)
 

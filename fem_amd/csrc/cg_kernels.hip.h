@@ -1525,30 +1525,35 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     return x ^ (x >> 31);
 }
 
-// checksum over the reference's view of the columns: len counts layers (not gaps) and every
-// layer contributes (mat, z0q, z1q)
+// Checksum over the reference's view of the columns.  Column c contributes
+//     mix(hg ^ TAG ^ layers) + sum over its layers of mix(hg ^ (mat | z0q << 8 | z1q << 24)),   hg = mix(global column index),
+// gaps not counted: a sum, so the intervals can be taken in any order -- bottom-up through the planes of the whole
+// form, top-down along the chain of the split form -- with every record loaded once and nothing kept per column.
+constexpr unsigned long long CHECKSUM_COUNT_TAG = 0xC01C0DEull << 40;
 __global__ __launch_bounds__(256) void k_checksum(GridView g, unsigned long long* __restrict__ out) {
     unsigned long long sum = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
-        unsigned long long gc = (unsigned long long)g.i0 * g.ny + c;
-        const int l = g.len[c];
-        uint32_t col[256];
-        load_column(g, c, l, col);
-        int layers = 0;
-        for (int k = 0; k < l; k++) layers += !rec_hole(col[k]);
-        unsigned long long h = splitmix64(gc);
-        h = splitmix64(h ^ (unsigned long long)layers);
-        unsigned prev = 0;
-        for (int k = 0; k < l; k++) {
-            const uint32_t r = col[k];
-            if (!rec_hole(r)) {
-                unsigned long long v = (unsigned long long)rec_mat(r) | ((unsigned long long)prev << 8) | ((unsigned long long)rec_z1(r) << 24);
-                h = splitmix64(h ^ v);
+        const unsigned long long hg = splitmix64((unsigned long long)g.i0 * g.ny + c);
+        unsigned long long h = 0; unsigned layers = 0;
+        if (!g.split) {
+            const int l = g.len[c];
+            unsigned prev = 0;
+            for (int k = 0; k < l; k++) {
+                const uint32_t r = g.rec[(size_t)k * g.N + c];
+                if (!rec_hole(r)) { h += splitmix64(hg ^ ((unsigned long long)rec_mat(r) | ((unsigned long long)prev << 8) | ((unsigned long long)rec_z1(r) << 24))); layers++; }
+                prev = rec_z1(r);
             }
-            prev = rec_z1(r);
+        } else {
+            uint32_t r = g.top[c];
+            for (int guard = 0; r != 0 && guard < 256; guard++) {
+                const int p = rec_lnk(r);
+                const uint32_t below = p != LNK_NONE ? g.rec[(size_t)p * g.N + c] : 0u;
+                if (!rec_hole(r)) { h += splitmix64(hg ^ ((unsigned long long)rec_mat(r) | ((unsigned long long)rec_z1(below) << 8) | ((unsigned long long)rec_z1(r) << 24))); layers++; }
+                r = below;
+            }
         }
-        sum += h;
+        sum += h + splitmix64(hg ^ CHECKSUM_COUNT_TAG ^ (unsigned long long)layers);
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, sum);
@@ -1812,11 +1817,12 @@ __global__ void k_edit_column(GridView g, size_t c, int op, int mat, unsigned z0
 // ------------------------------------------------------------------------------------------
 // layout conversion: device intervals <-> the reference's column-major host layout
 // ------------------------------------------------------------------------------------------
-// One column (l device intervals in col[]) as a row of the reference layout: L slots of mat and of
+// One column (l device intervals, interval k = at(k), asked for in rising k, each once) as a row of the reference layout: L slots of mat and of
 // (z0, z1), gaps skipped, slots past the last layer zero.  Returns the number of layers.  When L
 // is a multiple of 4 the row goes out as 4-byte / 16-byte stores (rows of neighbouring threads are
 // adjacent, so a wave fills whole lines); scalar stores otherwise.
-__device__ __forceinline__ int store_reference_row(const uint32_t* col, int l, int L, uint8_t* __restrict__ mrow, uint16_t* __restrict__ zrow) {
+template <class At>
+__device__ __forceinline__ int store_reference_row(At at, int l, int L, uint8_t* __restrict__ mrow, uint16_t* __restrict__ zrow) {
     int w = 0; unsigned prev = 0;
     if ((L & 3) == 0) {
         int k = 0;
@@ -1825,7 +1831,7 @@ __device__ __forceinline__ int store_reference_row(const uint32_t* col, int l, i
             for (int q = 0; q < 4; q++) {
                 uint32_t r = 0; bool have = false;
                 while (k < l) {
-                    r = col[k++];
+                    r = at(k++);
                     if (!rec_hole(r)) { have = true; break; }
                     prev = rec_z1(r);
                 }
@@ -1842,12 +1848,26 @@ __device__ __forceinline__ int store_reference_row(const uint32_t* col, int l, i
         return w;
     }
     for (int k = 0; k < l; k++) {
-        const uint32_t r = col[k];
+        const uint32_t r = at(k);
         if (!rec_hole(r) && w < L) { mrow[w] = (uint8_t)rec_mat(r); zrow[2 * w] = (uint16_t)prev; zrow[2 * w + 1] = (uint16_t)rec_z1(r); w++; }
         prev = rec_z1(r);
     }
     for (int k = w; k < L; k++) { mrow[k] = 0; zrow[2 * k] = 0; zrow[2 * k + 1] = 0; }
     return w;
+}
+
+// One column into a row of the reference layout.  The whole form is read plane by plane as the row is written; the
+// split form's chain runs top-down, so its intervals (at most LNK_NONE + 1) are first collected in a small per-lane array.
+__device__ __forceinline__ int gather_column(const GridView& g, size_t c, int count_chain, int L, uint8_t* __restrict__ mrow, uint16_t* __restrict__ zrow) {
+    if (g.split) {
+        uint32_t col[LNK_NONE + 1];
+        const int l = min(count_chain ? chain_length(g, c) : (int)g.len[c], LNK_NONE + 1);
+        load_column(g, c, l, col);
+        return store_reference_row([&](int k) { return col[k]; }, l, L, mrow, zrow);
+    }
+    const uint32_t* __restrict__ rc = g.rec + c;
+    const size_t N = g.N;
+    return store_reference_row([=](int k) { return rc[(size_t)k * N]; }, (int)g.len[c], L, mrow, zrow);
 }
 
 // Gather `ncols` columns (column s of the output is device column col0 + s*col_stride) into
@@ -1859,10 +1879,7 @@ __global__ __launch_bounds__(256) void k_gather_columns(GridView g, size_t col0,
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < ncols; s += stride) {
         const size_t c = col0 + s * col_stride;
-        const int l = count_chain ? chain_length(g, c) : (int)g.len[c];
-        uint32_t col[256];
-        load_column(g, c, l, col);
-        olen[s] = (uint8_t)store_reference_row(col, l, L, omat + s * (size_t)L, ozp + 2 * s * (size_t)L);
+        olen[s] = (uint8_t)gather_column(g, c, count_chain, L, omat + s * (size_t)L, ozp + 2 * s * (size_t)L);
     }
 }
 
@@ -1876,10 +1893,7 @@ __global__ __launch_bounds__(256) void k_gather_slices(GridView g, int axis, con
     for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
         const size_t q = s / line, p = s - q * line;
         const size_t c = axis == 0 ? (size_t)index[q] * g.ny + p : p * g.ny + (size_t)index[q];
-        const int l = count_chain ? chain_length(g, c) : (int)g.len[c];
-        uint32_t col[256];
-        load_column(g, c, l, col);
-        olen[s] = (uint8_t)store_reference_row(col, l, L, omat + s * (size_t)L, ozp + 2 * s * (size_t)L);
+        olen[s] = (uint8_t)gather_column(g, c, count_chain, L, omat + s * (size_t)L, ozp + 2 * s * (size_t)L);
     }
 }
 
@@ -1920,9 +1934,9 @@ __global__ __launch_bounds__(256) void k_scatter_columns(GridView g, size_t col0
 __global__ __launch_bounds__(256) void k_demote(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
-        const int l = g.len[c];
+        const int l = min((int)g.len[c], LNK_NONE + 1);     // (the split form holds no taller column)
         if (l == 0) continue;
-        uint32_t col[256];
+        uint32_t col[LNK_NONE + 1];
         load_column(g, c, l, col);
         for (int k = 0; k < l; k++) g.rec[(size_t)k * g.N + c] = col[k];
     }

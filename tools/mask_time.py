@@ -17,11 +17,13 @@ g = fem.ColumnGrid(2.0 * n, 2.0 * n, 2, 2)
 dev = torch.device("cuda", 0)
 for name in ("M", "Mshift", "Mc", "Mr"):
     t0 = time.time()
-    red = fem.reduce_mask(flows.shapes_of(specs[name], 2 * n, 2 * n))
+    data = flows.shapes_of(specs[name], 2 * n, 2 * n)
+    t0 = time.time()
+    red = fem.reduce_mask(data, packed=True)
     t1 = time.time()
     m = g.mask_from_shapes(red)            # returns after the raster is complete
     t2 = time.time()
-    line = f"{name}: {len(red['shapes'])} shapes, host reduction {t1 - t0:.2f} s, cg_mask_from_shapes {1e3 * (t2 - t1):.1f} ms"
+    line = f"{name}: {len(red['shapes'])} shapes, reduce_mask {t1 - t0:.2f} s, mask_from_shapes {1e3 * (t2 - t1):.1f} ms"
     if specs[name]["kind"] != "shapes":
         want = flows.raster_torch(specs[name], n, n, 0, dev)
         got = torch.from_numpy(m.download()).to(dev)
