@@ -1525,35 +1525,71 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     return x ^ (x >> 31);
 }
 
-// Checksum over the reference's view of the columns.  Column c contributes
-//     mix(hg ^ TAG ^ layers) + sum over its layers of mix(hg ^ (mat | z0q << 8 | z1q << 24)),   hg = mix(global column index),
-// gaps not counted: a sum, so the intervals can be taken in any order -- bottom-up through the planes of the whole
-// form, top-down along the chain of the split form -- with every record loaded once and nothing kept per column.
-constexpr unsigned long long CHECKSUM_COUNT_TAG = 0xC01C0DEull << 40;
+// Checksum over the reference's view of the columns.  With hg = mix(global column index), column c contributes
+//     mix(hg + layers + sum over its layers of term(hg, mat | z0q << 8 | z1q << 24)),
+// gaps not counted.  The inner sum lets the intervals come in any order -- bottom-up through the planes of the whole
+// form, top-down along the chain of the split form -- with every record loaded once and nothing kept per column;
+// term() is two 32-bit multiplies (one-to-one in the interval for a given hg), the 64-bit mixing is spent once per column.
+__device__ __forceinline__ unsigned long long checksum_term(unsigned long long hg, uint32_t r, unsigned z0q) {
+    const uint32_t lo = rec_mat(r) | (z0q << 8) | (rec_z1(r) << 24), hi = rec_z1(r) >> 8;
+    const uint32_t a = (lo ^ (uint32_t)hg) * 0x9E3779B1u;
+    const uint32_t b = (hi ^ (uint32_t)(hg >> 32) ^ (a >> 16)) * 0x85EBCA77u;
+    return ((unsigned long long)a << 32) | b;
+}
+// A lane walks CHECKSUM_U columns side by side (a block takes CHECKSUM_U runs of 256 neighbouring columns), so that
+// CHECKSUM_U dependent loads are in flight per lane instead of one; every load of a wave is of neighbouring columns.
+constexpr int CHECKSUM_U = 8;
 __global__ __launch_bounds__(256) void k_checksum(GridView g, unsigned long long* __restrict__ out) {
+    constexpr int U = CHECKSUM_U;
     unsigned long long sum = 0;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
-        const unsigned long long hg = splitmix64((unsigned long long)g.i0 * g.ny + c);
-        unsigned long long h = 0; unsigned layers = 0;
+    const size_t span = (size_t)U * blockDim.x;
+    for (size_t base = (size_t)blockIdx.x * span; base < g.N; base += (size_t)gridDim.x * span) {
+        size_t c[U]; unsigned long long hg[U], h[U]; bool in[U];
+        #pragma unroll
+        for (int q = 0; q < U; q++) {
+            c[q] = base + (size_t)q * blockDim.x + threadIdx.x; in[q] = c[q] < g.N;
+            if (!in[q]) c[q] = 0;
+            hg[q] = splitmix64((unsigned long long)g.i0 * g.ny + c[q]); h[q] = hg[q];
+        }
         if (!g.split) {
-            const int l = g.len[c];
-            unsigned prev = 0;
-            for (int k = 0; k < l; k++) {
-                const uint32_t r = g.rec[(size_t)k * g.N + c];
-                if (!rec_hole(r)) { h += splitmix64(hg ^ ((unsigned long long)rec_mat(r) | ((unsigned long long)prev << 8) | ((unsigned long long)rec_z1(r) << 24))); layers++; }
-                prev = rec_z1(r);
+            int l[U], lm = 0; unsigned prev[U];
+            #pragma unroll
+            for (int q = 0; q < U; q++) { l[q] = in[q] ? (int)g.len[c[q]] : 0; lm = max(lm, l[q]); prev[q] = 0; }
+            for (int k = 0; k < lm; k++) {
+                uint32_t r[U];
+                #pragma unroll
+                for (int q = 0; q < U; q++) r[q] = k < l[q] ? g.rec[(size_t)k * g.N + c[q]] : 0u;
+                #pragma unroll
+                for (int q = 0; q < U; q++) {
+                    if (k >= l[q]) continue;
+                    if (!rec_hole(r[q])) h[q] += checksum_term(hg[q], r[q], prev[q]) + 1;
+                    prev[q] = rec_z1(r[q]);
+                }
             }
         } else {
-            uint32_t r = g.top[c];
-            for (int guard = 0; r != 0 && guard < 256; guard++) {
-                const int p = rec_lnk(r);
-                const uint32_t below = p != LNK_NONE ? g.rec[(size_t)p * g.N + c] : 0u;
-                if (!rec_hole(r)) { h += splitmix64(hg ^ ((unsigned long long)rec_mat(r) | ((unsigned long long)rec_z1(below) << 8) | ((unsigned long long)rec_z1(r) << 24))); layers++; }
-                r = below;
+            uint32_t r[U];
+            #pragma unroll
+            for (int q = 0; q < U; q++) r[q] = in[q] ? g.top[c[q]] : 0u;
+            for (int guard = 0; guard < 256; guard++) {
+                bool any = false;
+                #pragma unroll
+                for (int q = 0; q < U; q++) any |= r[q] != 0;
+                if (!any) break;
+                uint32_t below[U];
+                #pragma unroll
+                for (int q = 0; q < U; q++) {
+                    const int p = rec_lnk(r[q]);
+                    below[q] = (r[q] != 0 && p != LNK_NONE) ? g.rec[(size_t)p * g.N + c[q]] : 0u;
+                }
+                #pragma unroll
+                for (int q = 0; q < U; q++) {
+                    if (r[q] != 0 && !rec_hole(r[q])) h[q] += checksum_term(hg[q], r[q], rec_z1(below[q])) + 1;
+                    r[q] = below[q];
+                }
             }
         }
-        sum += h + splitmix64(hg ^ CHECKSUM_COUNT_TAG ^ (unsigned long long)layers);
+        #pragma unroll
+        for (int q = 0; q < U; q++) if (in[q]) sum += splitmix64(h[q]);
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, sum);

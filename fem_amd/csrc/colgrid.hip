@@ -2255,7 +2255,7 @@ int cg_checksum(cg_grid* g, uint64_t* sum) {
     if (!sum) return fail(g, CG_ERR_ARG, "null output");
     if (!g->split) { int rc = ensure_len(g); if (rc) return rc; }       // (the split form's chains say where a column ends)
     HIPCHK(g, hipMemsetAsync(g->d_sum, 0, sizeof(unsigned long long), g->stream));
-    hipLaunchKernelGGL(k_checksum, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_sum);
+    hipLaunchKernelGGL(k_checksum, dim3(blocks_for((g->N + CHECKSUM_U - 1) / CHECKSUM_U)), dim3(256), 0, g->stream, view(g), g->d_sum);
     HIPCHK(g, hipGetLastError());
     unsigned long long h = 0;
     HIPCHK(g, hipMemcpyAsync(&h, g->d_sum, sizeof h, hipMemcpyDeviceToHost, g->stream));

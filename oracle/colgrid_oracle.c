@@ -854,21 +854,25 @@ static uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 
-/* same definition as cg_checksum of the engine: column c contributes
- *   mix(hg ^ TAG ^ len) + sum over its layers of mix(hg ^ (mat | z0q << 8 | z1q << 24)),  hg = mix(global column index) */
+/* same definition as cg_checksum of the engine: with hg = mix(global column index), column c contributes
+ *   mix(hg + len + sum over its layers of term(hg, mat | z0q << 8 | z1q << 24)) */
+static uint64_t checksum_term(uint64_t hg, uint32_t mat, uint32_t z0, uint32_t z1) {
+    uint32_t lo = mat | (z0 << 8) | (z1 << 24), hi = z1 >> 8;
+    uint32_t a = (lo ^ (uint32_t)hg) * 0x9E3779B1u;
+    uint32_t b = (hi ^ (uint32_t)(hg >> 32) ^ (a >> 16)) * 0x85EBCA77u;
+    return ((uint64_t)a << 32) | b;
+}
 uint64_t og_checksum(const og_grid *g) {
     uint64_t sum = 0; size_t N = (size_t)g->NX * g->NY;
-    const uint64_t TAG = 0xC01C0DEull << 40;
     for (size_t c = 0; c < N; c++) {
         uint64_t hg = splitmix64((uint64_t)g->i0 * g->NY + c);
         int l = g->len[c];
-        uint64_t h = splitmix64(hg ^ TAG ^ (uint64_t)l);
+        uint64_t h = hg + (uint64_t)l;
         for (int k = 0; k < l; k++) {
             size_t b = c * g->Lmax + k;
-            uint64_t v = (uint64_t)g->mat[b] | ((uint64_t)g->zpair[2 * b] << 8) | ((uint64_t)g->zpair[2 * b + 1] << 24);
-            h += splitmix64(hg ^ v);
+            h += checksum_term(hg, g->mat[b], g->zpair[2 * b], g->zpair[2 * b + 1]);
         }
-        sum += h;
+        sum += splitmix64(h);
     }
     return sum;
 }
