@@ -1720,11 +1720,17 @@ __global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh, int ma
     }
 }
 
-// one relaxation sweep: an unmarked node next to an overlapping marked node becomes marked
-__global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand, int* __restrict__ changed) {
+// One relaxation sweep: an unmarked node next to an overlapping marked node becomes marked, seeing whatever marks of
+// this same sweep have already become visible.  Marks only ever get added and the closure is unique, so the order in
+// which they spread does not matter; blocks start roughly in index order, so a sweep carries marks a long way in the
+// direction it runs, and the host alternates the direction (reverse: from the last column down) until a sweep changes
+// nothing.  (Relaxing a tile to its own fixpoint inside one launch was tried: lanes of a wave run in step, a mark moves
+// one column per pass along a row, and the tiles that do change cost up to a tile's width in passes: 2x slower overall.)
+__global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand, int reverse, int* __restrict__ changed) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     int any = 0;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+    for (size_t cc = (size_t)blockIdx.x * blockDim.x + threadIdx.x; cc < g.N; cc += stride) {
+        const size_t c = reverse ? g.N - 1 - cc : cc;
         if (!cand[c]) continue;
         const int l = g.len[c];
         bool open_node = false;

@@ -1571,15 +1571,18 @@ int cg_strip_sweep(cg_grid* g, int mat, int planes, const void* ghost_lower, con
     const dim3 grid(blocks_for(g->N)), blk(256);
     const Ghost gh = make_ghost(g, planes, ghost_lower, ghost_upper);
     int any = 0;
-    // relax to the local fixpoint; the flag is read back once per batch of sweeps
+    // Relax to the local fixpoint.  Sweeps go out four at a time, up and down the columns in turn, each with a flag word
+    // of its own; the words are read back together and the flood is over when the last sweep of a batch changed nothing
+    // (the closure is a fixpoint of every sweep, whichever way it runs).
     for (int round = 0;; round++) {
         if (round > 1000000) return fail(g, CG_ERR_STATE, "strip_connected did not converge");
-        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, sizeof(int), g->stream));
-        for (int sweep = 0; sweep < 4; sweep++) hipLaunchKernelGGL(k_strip_flood, grid, blk, 0, g->stream, view(g), gh, mat, g->cand, g->d_flags);
+        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+        for (int sweep = 0; sweep < 4; sweep++)
+            hipLaunchKernelGGL(k_strip_flood, grid, blk, 0, g->stream, view(g), gh, mat, g->cand, sweep & 1, g->d_flags + sweep);
         HIPCHK(g, hipGetLastError());
         int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
-        if (!fl[0]) break;
-        any = 1;
+        if (fl[0] || fl[1] || fl[2] || fl[3]) any = 1;
+        if (!fl[3]) break;
     }
     if (changed) *changed = any;
     return CG_OK;
