@@ -132,9 +132,15 @@ struct WetOut {                                                // merge of touch
     }
 };
 
+// The removal intervals the neighbours throw at a column are collected once (up to WET_CUTS of them per lane, in LDS,
+// as q0 | q1 << 16: both are at most Hq < 65536) and walked from there for every piece of every target layer; a column
+// that receives more goes back to its neighbours each time.
+constexpr int WET_CUTS = 24;
 __global__ __launch_bounds__(256) void k_wet_step(GridView s, Ghost gh, GridView d, int matId, int dtQ, int dtQDiag, int diag, unsigned Hq,
                                                   int* __restrict__ flags) {
+    __shared__ uint32_t s_cut[WET_CUTS][256];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int tid = threadIdx.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < s.N; c += stride) {
         const int l = s.len[c];
         const int i = (int)(c / s.ny), j = (int)(c - (size_t)i * s.ny);
@@ -154,8 +160,12 @@ __global__ __launch_bounds__(256) void k_wet_step(GridView s, Ghost gh, GridView
             }
             if (seg_below && wet_target(matId, below_m)) any = true;
         }
-        if (!any) for_each_lateral_cut(s, gh, i, j, Hq, dtQDiag, diag != 0, [&](int, int) { any = true; });
-        if (!any) { copy_column(s, d, c, flags); continue; }
+        int ncut = 0;
+        for_each_lateral_cut(s, gh, i, j, Hq, dtQDiag, diag != 0, [&](int q0, int q1) {
+            if (ncut < WET_CUTS) s_cut[ncut][tid] = (uint32_t)q0 | ((uint32_t)q1 << 16);
+            ncut++;
+        });
+        if (!any && ncut == 0) { copy_column(s, d, c, flags); continue; }
 
         WetOut out(d, c);
         unsigned prev = 0;
@@ -193,7 +203,8 @@ __global__ __launch_bounds__(256) void k_wet_step(GridView s, Ghost gh, GridView
                     else if (a < nxt) nxt = a;
                 };
                 see(vt0, vt1); see(vb0, vb1);
-                for_each_lateral_cut(s, gh, i, j, Hq, dtQDiag, diag != 0, see);
+                if (ncut <= WET_CUTS) { for (int q = 0; q < ncut; q++) { const uint32_t v = s_cut[q][tid]; see((int)(v & 0xffffu), (int)(v >> 16)); } }
+                else for_each_lateral_cut(s, gh, i, j, Hq, dtQDiag, diag != 0, see);
                 if (cover > cur) { cur = cover; continue; }
                 out.put((unsigned)cur, (unsigned)nxt, m);
                 cur = nxt;
@@ -452,13 +463,17 @@ __device__ __forceinline__ void insert_runs(const GridView& s, const GridView& d
     out.W.finish(d.len, flags);
 }
 
-struct AldTap { int du, dv; double add; };
+// One tap of the coat kernel: a seed [x, y] (height steps) at offset (du, dv) grows to [x*zs - add, y*zs + add], is clipped
+// to [0, Hcap] and quantised (cg2:542-557).  exact: the host has checked that the quantised ends are x - lo_q and y + hi_q
+// for EVERY integer x, y (add / zs is further than 1e-6 from a rounding boundary, where the double arithmetic of the
+// reference, good to 1e-10 steps here, cannot end on the other side), so the kernel works in integers for this tap.
+struct AldTap { int du, dv; double add; int lo_q, hi_q, exact, pad_; };
 
 // --- coat at thickness t (computeCoatBitsSingleT + applyCoatFromBits, cg2:699-707, 585-682) --
 // bbox = the seeds' bounding box grown by the kernel radius and clipped to the domain (cg2:510-524).
 __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, const AldTap* __restrict__ taps, int ntaps,
                            const uint16_t* __restrict__ seed_n, const uint2* __restrict__ seed, int seed_planes, ArrLayout S,
-                           int imin, int imax, int jmin, int jmax, int mat, int* __restrict__ flags) {
+                           int imin, int imax, int jmin, int jmax, int mat, int HcapQ, int* __restrict__ flags) {
     extern __shared__ uint32_t lds[];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const BitCol fill{lds + threadIdx.x, (int)blockDim.x, L.wpc};
@@ -475,7 +490,17 @@ __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, con
             if (uhave) mark_range_q(fill, ua, ub);
             ua = q0; ub = q1; uhave = true;
         };
-        auto grow_seed = [&](const uint2 sd, const double add) {  // cg2:542-557
+        auto grow_seed = [&](const uint2 sd, const AldTap& tp) {  // cg2:542-557
+            // In integers when the tap allows it and the lower end stays a step clear of the cap (neither of the
+            // reference's two "empty after clipping" exits can then be taken: the range is 2*add > 1e-6 long before
+            // clipping, and at least most of a step long after it).
+            if (tp.exact && (int)sd.x - tp.lo_q < HcapQ - 1) {
+                const int q0 = max(0, (int)sd.x - tp.lo_q);
+                int q1 = min(HcapQ, (int)sd.y + tp.hi_q); if (q1 <= q0) q1 = q0 + 1;
+                add_range(q0, q1);
+                return;
+            }
+            const double add = tp.add;
             const double lo = (double)sd.x * s.zs - add, hi = (double)sd.y * s.zs + add;
             if (hi <= lo + CG_EPS) return;
             const double z0 = lo > 0 ? lo : 0, z1 = hi < Hcap ? hi : Hcap;
@@ -493,35 +518,34 @@ __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, con
                 const int tend = min(ntaps, tc + 64);
                 unsigned long long more = 0;
                 for (int t0 = tc; t0 < tend; t0 += 4) {
-                    size_t sc[4]; int ns[4]; uint2 first[4]; double add[4];
+                    size_t sc[4]; int ns[4]; uint2 first[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        ns[u] = 0; sc[u] = 0; add[u] = 0;
+                        ns[u] = 0; sc[u] = 0;
                         if (t0 + u >= tend) continue;
                         const int si = i - taps[t0 + u].du, sj = j - taps[t0 + u].dv;
                         if (si < -S.rows_lo || sj < 0 || si >= s.nx + S.rows_hi || sj >= s.ny) continue;
                         sc[u] = S.at(s, si, sj);
                         ns[u] = min((int)seed_n[sc[u]], seed_planes);
-                        add[u] = taps[t0 + u].add;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) first[u] = ns[u] > 0 ? seed[sc[u]] : make_uint2(0u, 0u);
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        if (ns[u] > 0) grow_seed(first[u], add[u]);
+                        if (ns[u] > 0) grow_seed(first[u], taps[min(t0 + u, tend - 1)]);
                         if (ns[u] > 1) more |= 1ull << (t0 + u - tc);
                     }
                 }
-                int q = 0, n = 0; size_t scl = 0; double addl = 0;
+                int q = 0, n = 0; size_t scl = 0; AldTap tpl = taps[tc];
                 for (;;) {
                     if (q >= n) {
                         if (!more) break;
-                        const AldTap tp = taps[tc + __builtin_ctzll(more)];
+                        tpl = taps[tc + __builtin_ctzll(more)];
                         more &= more - 1;
-                        scl = S.at(s, i - tp.du, j - tp.dv); addl = tp.add;
+                        scl = S.at(s, i - tpl.du, j - tpl.dv);
                         n = min((int)seed_n[scl], seed_planes); q = 1;
                     }
-                    grow_seed(seed[(size_t)q * S.stride + scl], addl); q++;
+                    grow_seed(seed[(size_t)q * S.stride + scl], tpl); q++;
                 }
             }
         if (uhave) mark_range_q(fill, ua, ub);

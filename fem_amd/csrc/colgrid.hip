@@ -883,7 +883,7 @@ int build_ald_taps(const cg_grid* g, double t, std::vector<AldTap>* taps) {
             const double y = dv * g->dy;
             double add = rem - (y * y);
             if (add < 0) add = 0;
-            taps->push_back(AldTap{du, dv, std::sqrt(add)});
+            taps->push_back(AldTap{du, dv, std::sqrt(add), 0, 0, 0, 0});
         }
     }
     return Rx;
@@ -905,6 +905,15 @@ int ald_coat(cg_grid* g, int mat, double t, const uint32_t* hmax_q = nullptr) {
     if (!bt) return fail(g, CG_ERR_UNSUPPORTED, "deposit_ALD: %d height bins per column do not fit the bitsets", L.Zmax);
     std::vector<AldTap> taps;
     const int Rx = build_ald_taps(g, t, &taps);
+    // the taps whose quantised range ends are the seed's ends moved by whole steps, whatever the seed (see AldTap)
+    const double inv_zs = 1.0 / g->zscale;
+    const int HcapQ = (int)std::min(2.0e9, js_round(Hcap * inv_zs));
+    static const bool no_int = getenv("CG_ALD_NOINT") != nullptr;
+    for (AldTap& tp : taps) {
+        const double a = tp.add * inv_zs, f = a - std::floor(a);
+        tp.exact = (!no_int && tp.add > 1e-6 && a < 1.0e6 && std::fabs(f - 0.5) > 1e-6 && g->zscale > 1e-6 && Hcap > 1e-6) ? 1 : 0;
+        tp.lo_q = (int)std::ceil(std::min(a, 1.0e6) - 0.5); tp.hi_q = (int)std::floor(std::min(a, 1.0e6) + 0.5);
+    }
     if ((int)taps.size() > g->ald_taps_cap) {
         HIPCHK(g, hipStreamSynchronize(g->stream));
         if (g->d_ald_taps) (void)hipFree(g->d_ald_taps);
@@ -925,7 +934,7 @@ int ald_coat(cg_grid* g, int mat, double t, const uint32_t* hmax_q = nullptr) {
     ProfScope ps(g, CG_K_OTHER);
     return run_out_of_place(g, 0, "deposit_ALD", [&](GridView dst) {
         hipLaunchKernelGGL(k_ald_coat, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), dst, L, Hcap, g->d_ald_taps, ntaps,
-                           g->seed_n, g->seed, g->seed_planes, seed_layout(g), imin, imax, jmin, jmax, mat, g->d_flags);
+                           g->seed_n, g->seed, g->seed_planes, seed_layout(g), imin, imax, jmin, jmax, mat, HcapQ, g->d_flags);
     });
 }
 
