@@ -1087,6 +1087,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
     constexpr int Rp = G::Rp, PITCH = G::PITCH, W = G::W, HG = G::HG, TP = STREAM_TAB_PITCH;
     __shared__ __align__(16) float s_row[2][PITCH];
     __shared__ __align__(16) float s_tab[(R + 1) * TP];
+    // The top records (etch: and mask bytes) of the last R + 2 input rows, as loaded for staging: input row r - R is the
+    // output row that input row r completes, and its records come from here instead of a second trip to memory (which
+    // missed the L2 more often than not: 2R rows of every resident wave lie between the two uses).
+    // (Deposits up to R = 6.  Beyond, the ring would cost a resident wave per compute unit, and those kernels wait on
+    // arithmetic; the etch, whose update starts with loads that depend on these records, measured 6 % slower with it.)
+    constexpr bool RINGED = !ETCH && R <= 6;
+    constexpr int RING = RINGED ? R + 2 : 1;
+    __shared__ __align__(16) uint32_t s_top[RING][64 * 4];
+    __shared__ unsigned s_msk[ETCH ? RING : 1][64];
     const int tiles_j = (g.ny + STRIP - 1) / STRIP;
     int tile_i, tile_j;
     if (!tile_of_block(g, tiles_j, tile_i, tile_j)) return;
@@ -1125,6 +1134,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
     if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
     *(float4*)(s_row[0] + Rp + 4 * lane) = stream_heights<ETCH>(g, so, in_m, false, m_right, matId, isAll);
     if (has_halo) *(float4*)(s_row[0] + h_at) = stream_heights<ETCH>(g, so, in_h, h_left, h_right, matId, isAll);
+    if (RINGED) { *(u32x4*)(s_top[0] + 4 * lane) = in_m.a; if (ETCH) s_msk[0][lane] = in_m.m; }
     if (1 < rows_in) {
         in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + 1, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);
         if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + 1, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
@@ -1151,7 +1161,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
         // last column load a copy of the edge group: every lane takes part, only their stores are left out)
         const size_t c0 = (size_t)(i_base + (FIN ? r - 2 * R : 0)) * g.ny + m_jc;
         u32x4 tv = (u32x4)(0); unsigned mk = 0x01010101u;
-        if (FIN) { tv = ld_rec4(g.top + c0); if (MASKED) mk = *(const unsigned*)(mask + c0); }
+        if (FIN && !RINGED) tv = ld_rec4(g.top + c0);
+        if (FIN && MASKED && !(ETCH && RINGED)) mk = *(const unsigned*)(mask + c0);
         // ---- D[du] = op over dv of (p[dv] + a(du, dv)); row dv of the (symmetric) table lists the du's
         float D[R + 1][4];
 #pragma unroll
@@ -1187,7 +1198,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
         // ---- the output row centred on input row r - R is complete in A[0]: which of its columns take part
         // (The output row's columns arrive here on every path: a use that sat only inside the branches below would
         // leave them "maybe pending" at the loop head and cost a wait for everything there.)
-        if (FIN) asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(mk));
+        if (FIN) {
+            if (RINGED) {
+                const int slot = (r - R) % RING;
+                tv = *(const u32x4*)(s_top[slot] + 4 * lane);
+                if (ETCH) mk = s_msk[slot][lane];
+            }
+            asm volatile("" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(mk));
+        }
         unsigned act = 0;
         uint32_t b4[4] = {0, 0, 0, 0};
         if (FIN) {
@@ -1205,6 +1223,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
             float* nxt = s_row[(r + 1) & 1];
             *(float4*)(nxt + Rp + 4 * lane) = stream_heights<ETCH>(g, so, in_m, false, m_right, matId, isAll);
             if (has_halo) *(float4*)(nxt + h_at) = stream_heights<ETCH>(g, so, in_h, h_left, h_right, matId, isAll);
+            if (RINGED) {
+                const int slot = (r + 1) % RING;
+                *(u32x4*)(s_top[slot] + 4 * lane) = in_m.a;
+                if (ETCH) s_msk[slot][lane] = in_m.m;
+            }
         }
         // (the records loaded above are looked at from here on, not before the staging)
         if (ETCH && FIN) asm volatile("" : "+v"(b4[0]), "+v"(b4[1]), "+v"(b4[2]), "+v"(b4[3]));
