@@ -4,11 +4,11 @@
  * The library keeps one process-emulation grid per handle resident in HBM and runs
  * every process step as hand-written HIP kernels.  The grid is a 2-D array of columns
  * (index c = i*NY + j, j fastest); every column is a stack of (material, z0, z1) layers.
- * On the device a column is its top interval top[c] (u32: z1 | material << 16 | flags << 24)
- * and, plane-major, the intervals below it rec[p*N + c] (u32) chained through link[c] / prv[p*N + c]
- * (u8 plane indices), so that a wavefront touching the tops -- or the intervals one process step
- * laid down -- of neighbouring columns reads contiguous bytes; a layer's bottom is the top of
- * the interval below it.
+ * On the device a column is its top interval top[c] (u32: z1 | material << 16 | flags << 24 |
+ * plane of the interval below << 26) and, plane-major, the intervals below it rec[p*N + c] (u32,
+ * same format: every record names the plane of the one below it), so that a wavefront touching the
+ * tops -- or the intervals one process step laid down -- of neighbouring columns reads contiguous
+ * bytes; a layer's bottom is the top of the interval below it.
  * cg_download / cg_upload convert to and from the reference's host layout
  *     mat[c*Lmax + k],  zpair[2*(c*Lmax + k) + {0,1}],  len[c]
  * (reference: template/script_columngrid.js:84-86, 111-112).
@@ -376,8 +376,8 @@ int cg_step_stats(cg_grid* g, int enable, uint64_t stats[CG_NSTAT]);
 #define CG_K_ETCH_VERTICAL   1   /* k_vertical_g4<etch>                                          */
 #define CG_K_SNAPSHOT        2   /* not used any more (lateral steps read the tops directly)   */
 #define CG_K_HALO            3   /* k_halo_pack, k_ghost_pack                                  */
-#define CG_K_STENCIL_DEPOSIT 4   /* k_stencil_sym<deposit> (k_stencil_apply for radius > 8)     */
-#define CG_K_STENCIL_ETCH    5   /* k_stencil_sym<etch>                                          */
+#define CG_K_STENCIL_DEPOSIT 4   /* k_stencil_stream / k_stencil_sym <deposit> (k_stencil_apply for radius > 8) */
+#define CG_K_STENCIL_ETCH    5   /* k_stencil_stream / k_stencil_sym <etch>                        */
 #define CG_K_MASK            6   /* k_mask_shapes                                              */
 #define CG_K_CLEAR           7   /* memsets of cg_reset / cg_clear                             */
 #define CG_K_REDUCE          8   /* k_max_top                                                  */
