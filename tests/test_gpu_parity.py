@@ -574,6 +574,85 @@ def test_columns_taller_than_64_intervals():
     g.close()
 
 
+def test_strip_connected_along_a_serpentine():
+    """A buried layer of material 4 that winds through the grid (full rows joined at alternating ends) and is open
+    to the air at one end only: the flood has to run the whole path, against and along the sweep direction, over many
+    batches of sweeps.  A second, closed loop of the same material must stay.  Against the oracle."""
+    fem = _engine()
+    nx, ny, lm = 41, 48, 32
+    n = nx * ny
+    ln = np.full(n, 3, np.uint8)
+    mat = np.zeros((n, lm), np.uint8); zp = np.zeros((n, lm, 2), np.uint16)
+    mat[:, 0] = 3; zp[:, 0] = (0, 100)
+    mat[:, 1] = 6; zp[:, 1] = (100, 150)
+    mat[:, 2] = 5; zp[:, 2] = (150, 200)
+    M = mat.reshape(nx, ny, lm)
+    for i in range(0, 33, 2):
+        M[i, 2:ny - 2, 1] = 4                                  # the runs ...
+        if i + 2 <= 32:
+            M[i + 1, (ny - 3) if (i // 2) % 2 == 0 else 2, 1] = 4   # ... and the bends
+    M[36:40, 10:20, 1] = 4; M[37:39, 11:19, 1] = 6             # a closed ring, never exposed
+    ln.reshape(nx, ny)[0, 2] = 2                               # the cap is missing over the first cell of the path
+    M[0, 2, 2] = 0; zp.reshape(nx, ny, lm, 2)[0, 2, 2] = (0, 0)
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    g.upload(ln, mat.reshape(-1), zp.reshape(-1), lm); o.upload(ln, mat.reshape(-1), zp.reshape(-1), lm)
+    g.strip_connected(4); o.strip_connected(4)
+    oa = o.arrays()
+    _assert_same(g, oa, "strip along the path")
+    left = (oa[1].reshape(nx, ny, -1)[:, :, :3] == 4).any(axis=2)
+    assert not left[:34].any() and left[36:40].any()           # the whole path went, the ring stayed
+    g.close()
+
+
+def _layered_columns(nx, ny, lm, layers, seed):
+    """Every column `layers` layers on a 5 nm pitch whose ends are pulled in by 0 .. 0.8 nm each (so most
+    neighbouring layers are parted by a thin gap, at slightly different heights from column to column); one column
+    in seven is a single solid layer of the same height instead."""
+    rng = np.random.default_rng(seed)
+    n, P = nx * ny, 50
+    ln = np.full(n, layers, np.uint8)
+    mat = np.zeros((n, lm), np.uint8); zp = np.zeros((n, lm, 2), np.uint16)
+    for c in range(n):
+        if rng.random() < 1 / 7:
+            ln[c] = 1; mat[c, 0] = 3; zp[c, 0] = (0, layers * P)
+            continue
+        for k in range(layers):
+            z0 = k * P + (int(rng.integers(0, 9)) if k > 0 else 0)
+            z1 = (k + 1) * P - int(rng.integers(0, 9))
+            mat[c, k] = int(rng.integers(3, 7)); zp[c, k] = (z0, z1)
+    return ln, mat.reshape(-1), zp.reshape(-1)
+
+
+@pytest.mark.parametrize("seed,layers", [(5, 15), (6, 2)])
+def test_wet_etch_and_ald_on_many_layered_columns(seed, layers):
+    """Uploaded columns of 15 layers with thin gaps between them (layers + gaps + the cavity pass's top piece stay within
+    Lmax = 32, which the reference does not check, script_columngrid2.js:60-69): a column's 8 neighbours then throw far more removal
+    intervals at it than the wet-etch kernel keeps per lane (it goes back to the neighbours' records for those
+    columns); with 2 layers everything stays within the list.  The ALD coat meets tens of seeds per neighbour.
+    Against the oracle on the full arrays."""
+    fem = _engine()
+    nx, ny, lm = 28, 24, 32
+    ln, mat, zp = _layered_columns(nx, ny, lm, layers, seed)
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    g.upload(ln, mat, zp, lm); o.upload(ln, mat, zp, lm)
+    assert g.checksum() == o.checksum()
+    g.etch_wet(255, 0.4, dt=0.2); o.etch_wet(255, 0.4, dt=0.2)
+    _assert_same(g, o.arrays(), "etch_wet(ALL)")
+    assert o.arrays()[0].max() >= layers                       # (the stacks are still there)
+    g.etch_wet(4, 0.5); o.etch_wet(4, 0.5)
+    _assert_same(g, o.arrays(), "etch_wet(4)")
+    # the coat adds up to two pieces per gap: fewer layers, so that the columns stay within Lmax
+    ln, mat, zp = _layered_columns(nx, ny, lm, min(layers, 6), seed + 100)
+    g.upload(ln, mat, zp, lm); o.upload(ln, mat, zp, lm)
+    g.deposit_ALD(6, 1.1, dt=0.6); o.deposit_ALD(6, 1.1, dt=0.6)
+    _assert_same(g, o.arrays(), "deposit_ALD")
+    g.etch_wet(6, 0.3); o.etch_wet(6, 0.3)
+    _assert_same(g, o.arrays(), "etch_wet(6) after the coat")
+    g.close()
+
+
 @pytest.mark.parametrize("dx,zs,lmax", [(1.0, 0.1, 32), (2.0, 0.05, 32), (3.0, 0.25, 16), (0.5, 0.2, 32), (2.0, 0.1, 4), (2.0, 0.1, 1)])
 def test_other_pitches_and_height_steps(dx, zs, lmax):
     """Cell pitch and height quantum other than the defaults (2 nm, 0.1 nm), small initial Lmax
