@@ -228,22 +228,41 @@ struct BitCol {
     __device__ void clear() const { for (int w = 0; w < wpc; w++) base[w * stride] = 0; }
 };
 
+// The same column written by OTHER lanes of the wave (they OR ranges in for its owner): LDS atomics.
+struct BitColShared {
+    uint32_t* base; int stride; int wpc;
+    __device__ void orw(int w, uint32_t v) const { if ((unsigned)w < (unsigned)wpc && v) atomicOr(&base[w * stride], v); }
+    __device__ void set(int w, uint32_t v) const { atomicOr(&base[w * stride], v); }          // (only ever all ones)
+};
+
 __device__ __forceinline__ uint32_t js_shl1(int n) { return 1u << (n & 31); }          // 1 << n in JavaScript
 
 // markRangeQ (cg2:170-184).  Words outside the column are dropped.  CLEAR: the bits markRangeQ would
 // set are cleared instead, i.e. b &= ~(what marking an empty set would give).
-template <bool CLEAR = false>
-__device__ __forceinline__ void mark_range_q(const BitCol& b, int q0, int q1) {
+template <bool CLEAR = false, class B = BitCol>
+__device__ __forceinline__ void mark_range_q(const B& b, int q0, int q1) {
     if (q1 <= q0) return;
     const int w0 = (int)((unsigned)q0 >> 5), w1 = (int)((unsigned)(q1 - 1) >> 5);
     const int s0 = q0 & 31, s1 = (q1 - 1) & 31;
-    auto put = [&](int w, uint32_t m) { if (CLEAR) b.andn(w, m); else b.orw(w, m); };
+    auto put = [&](int w, uint32_t m) { if constexpr (CLEAR) b.andn(w, m); else b.orw(w, m); };
     if (w0 == w1) put(w0, (~(js_shl1(s0) - 1u)) & (js_shl1(s1 + 1) - 1u));
     else {
         put(w0, ~(js_shl1(s0) - 1u));
         for (int w = w0 + 1; w < w1; w++) if (w < b.wpc) b.set(w, CLEAR ? 0u : 0xFFFFFFFFu);
         put(w1, js_shl1(s1 + 1) - 1u);
     }
+}
+
+// Exactly the bits of [q0, q1), q1 > q0 (what markRangeQ does for a range that does not end on a word boundary).
+template <class B>
+__device__ __forceinline__ void mark_range_exact(const B& b, int q0, int q1) {
+    const int w0 = (int)((unsigned)q0 >> 5), w1 = (int)((unsigned)(q1 - 1) >> 5);
+    const int e1 = ((q1 - 1) & 31) + 1;                        // 1 .. 32 bits of the last word
+    const uint32_t lo = ~0u << (q0 & 31), hi = e1 == 32 ? ~0u : ((1u << e1) - 1u);
+    if (w0 == w1) { b.orw(w0, lo & hi); return; }
+    b.orw(w0, lo);
+    for (int w = w0 + 1; w < w1; w++) if (w < b.wpc) b.set(w, 0xFFFFFFFFu);
+    b.orw(w1, hi);
 }
 
 // qZ of deposit_ALD (cg2:144-145) applied to a de-quantised integer height
@@ -477,46 +496,57 @@ __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, con
     extern __shared__ uint32_t lds[];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const BitCol fill{lds + threadIdx.x, (int)blockDim.x, L.wpc};
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < s.N; c += stride) {
-        const int i = (int)(c / s.ny), j = (int)(c - (size_t)i * s.ny);
+    const int lane = threadIdx.x & 63, nl = min(64, (int)blockDim.x);      // lanes of this wave (a block is 2^k threads)
+    // the quantised range [q0, q1) a seed grows to under a tap, or false (cg2:542-557)
+    auto seed_range = [&](const uint2 sd, const AldTap& tp, int& q0, int& q1) -> bool {
+        // In integers when the tap allows it and the lower end stays a step clear of the cap (neither of the
+        // reference's two "empty after clipping" exits can then be taken: the range is 2*add > 1e-6 long before
+        // clipping, and at least most of a step long after it).
+        if (tp.exact && (int)sd.x - tp.lo_q < HcapQ - 1) {
+            q0 = max(0, (int)sd.x - tp.lo_q);
+            q1 = min(HcapQ, (int)sd.y + tp.hi_q); if (q1 <= q0) q1 = q0 + 1;
+            return true;
+        }
+        const double add = tp.add;
+        const double lo = (double)sd.x * s.zs - add, hi = (double)sd.y * s.zs + add;
+        if (hi <= lo + CG_EPS) return false;
+        const double z0 = lo > 0 ? lo : 0, z1 = hi < Hcap ? hi : Hcap;
+        if (z1 <= z0 + CG_EPS) return false;
+        double d0 = js_round(z0 * s.inv_zs); if (d0 < 0) d0 = 0;
+        double d1 = js_round(z1 * s.inv_zs); if (d1 <= d0) d1 = d0 + 1;
+        q0 = (int)d0; q1 = (int)d1;
+        return true;
+    };
+    // (the loop runs the same number of times in every lane: the lanes of a wave work together further down)
+    for (size_t base = (size_t)blockIdx.x * blockDim.x; base < s.N; base += stride) {
+        const size_t c = base + threadIdx.x;
+        const bool inside = c < s.N;
+        const int i = inside ? (int)(c / s.ny) : 0, j = inside ? (int)(c - (size_t)i * s.ny) : 0;
         fill.clear();
         // Neighbouring taps give ranges that overlap, so ranges are united in registers and reach the bitset
         // only when one starts away from the running union.  markRangeQ sets exactly the bits of [q0, q1) unless
-        // q1 is a multiple of 32 (see the top of this file); those ranges go to the bitset one by one, as they are.
+        // q1 is a multiple of 32 (see the top of this file): then its mask for the last word is empty, which leaves
+        // [q0, q1 - 32) if the range spans words and nothing if it does not.  United here are the bits really set.
+        // (One range in 32 ends like that: in a wave of 64 columns nearly every tap has one, so sending them to
+        // the bitset one by one made every lane wait through a marking pass per tap.)
         int ua = 0, ub = 0; bool uhave = false;
         auto add_range = [&](int q0, int q1) {
-            if ((q1 & 31) == 0) { mark_range_q(fill, q0, q1); return; }
+            if ((q1 & 31) == 0) { q1 -= 32; if (q1 <= q0) return; }
             if (uhave && q0 <= ub && q1 >= ua) { ua = min(ua, q0); ub = max(ub, q1); return; }
-            if (uhave) mark_range_q(fill, ua, ub);
+            if (uhave) mark_range_exact(fill, ua, ub);
             ua = q0; ub = q1; uhave = true;
         };
-        auto grow_seed = [&](const uint2 sd, const AldTap& tp) {  // cg2:542-557
-            // In integers when the tap allows it and the lower end stays a step clear of the cap (neither of the
-            // reference's two "empty after clipping" exits can then be taken: the range is 2*add > 1e-6 long before
-            // clipping, and at least most of a step long after it).
-            if (tp.exact && (int)sd.x - tp.lo_q < HcapQ - 1) {
-                const int q0 = max(0, (int)sd.x - tp.lo_q);
-                int q1 = min(HcapQ, (int)sd.y + tp.hi_q); if (q1 <= q0) q1 = q0 + 1;
-                add_range(q0, q1);
-                return;
-            }
-            const double add = tp.add;
-            const double lo = (double)sd.x * s.zs - add, hi = (double)sd.y * s.zs + add;
-            if (hi <= lo + CG_EPS) return;
-            const double z0 = lo > 0 ? lo : 0, z1 = hi < Hcap ? hi : Hcap;
-            if (z1 <= z0 + CG_EPS) return;
-            double q0 = js_round(z0 * s.inv_zs); if (q0 < 0) q0 = 0;
-            double q1 = js_round(z1 * s.inv_zs); if (q1 <= q0) q1 = q0 + 1;
-            add_range((int)q0, (int)q1);
-        };
-        if (i >= imin && i <= imax && j >= jmin && j <= jmax)
-            for (int tc = 0; tc < ntaps; tc += 64) {
-                // Most columns hold one seed, a few (pattern edges) many, and every wave meets some of those:
-                // the first seed of every tap is done in step by the whole wave, four taps' loads in flight
-                // together; the taps whose column holds more are noted in `more`, and each lane then works
-                // through its own at its own pace.
-                const int tend = min(ntaps, tc + 64);
-                unsigned long long more = 0;
+        const bool in_box = inside && i >= imin && i <= imax && j >= jmin && j <= jmax;
+        for (int tc = 0; tc < ntaps; tc += 64) {
+            // Most columns hold one seed per neighbour, a few (pattern edges) ten or twenty, and every wave meets some
+            // of those.  The first seed of every tap is done in step by the whole wave, four taps' loads in flight
+            // together, its ranges united in the lane's registers.  The (column, tap) pairs that hold more seeds are
+            // noted in `more` and then dealt out over ALL lanes of the wave, whoever owns the column: a lane ORs the
+            // ranges of its pairs into the owner's bitset (LDS atomics).  Left to their owners, these seeds kept a
+            // whole wave waiting for its busiest lane: two thirds of the kernel's instructions at 29 taps.
+            const int tend = min(ntaps, tc + 64);
+            unsigned long long more = 0;
+            if (in_box)
                 for (int t0 = tc; t0 < tend; t0 += 4) {
                     size_t sc[4]; int ns[4]; uint2 first[4];
 #pragma unroll
@@ -532,23 +562,46 @@ __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, con
                     for (int u = 0; u < 4; u++) first[u] = ns[u] > 0 ? seed[sc[u]] : make_uint2(0u, 0u);
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        if (ns[u] > 0) grow_seed(first[u], taps[min(t0 + u, tend - 1)]);
+                        int q0, q1;
+                        if (ns[u] > 0 && seed_range(first[u], taps[min(t0 + u, tend - 1)], q0, q1)) add_range(q0, q1);
                         if (ns[u] > 1) more |= 1ull << (t0 + u - tc);
                     }
                 }
-                int q = 0, n = 0; size_t scl = 0; AldTap tpl = taps[tc];
-                for (;;) {
-                    if (q >= n) {
-                        if (!more) break;
-                        tpl = taps[tc + __builtin_ctzll(more)];
-                        more &= more - 1;
-                        scl = S.at(s, i - tpl.du, j - tpl.dv);
-                        n = min((int)seed_n[scl], seed_planes); q = 1;
+            // ---- the pairs with more seeds, dealt out: pair number `it` belongs to the lane whose running count passes it
+            const int cnt = __popcll(more);
+            int incl = cnt;
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+            const int total = __shfl(incl, nl - 1, 64), excl = incl - cnt;
+            const unsigned more_lo = (unsigned)more, more_hi = (unsigned)(more >> 32);
+            for (int it0 = 0; it0 < total; it0 += nl) {
+                const int it = it0 + lane;
+                int owner = 0;                                  // lanes whose running count is <= it (the counts do not fall)
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int cand = owner + step;
+                    const int v = __shfl(incl, min(cand, nl) - 1, 64);
+                    if (cand <= nl && v <= it) owner = cand;
+                }
+                owner = min(owner, nl - 1);
+                const unsigned long long om = (unsigned long long)(unsigned)__shfl((int)more_lo, owner, 64)
+                                              | ((unsigned long long)(unsigned)__shfl((int)more_hi, owner, 64) << 32);
+                const int oex = __shfl(excl, owner, 64), oi = __shfl(i, owner, 64), oj = __shfl(j, owner, 64);
+                if (it < total) {
+                    unsigned long long m2 = om;
+                    for (int k = it - oex; k > 0; k--) m2 &= m2 - 1;
+                    const AldTap tp = taps[tc + __builtin_ctzll(m2)];
+                    const size_t scl = S.at(s, oi - tp.du, oj - tp.dv);
+                    const int n = min((int)seed_n[scl], seed_planes);
+                    const BitColShared ob{lds + ((int)threadIdx.x - lane + owner), (int)blockDim.x, L.wpc};
+                    for (int q = 1; q < n; q++) {
+                        int q0, q1;
+                        if (seed_range(seed[(size_t)q * S.stride + scl], tp, q0, q1)) mark_range_q<false, BitColShared>(ob, q0, q1);
                     }
-                    grow_seed(seed[(size_t)q * S.stride + scl], tpl); q++;
                 }
             }
-        if (uhave) mark_range_q(fill, ua, ub);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!inside) continue;
+        if (uhave) mark_range_exact(fill, ua, ub);
         mark_occupied<true>(s, c, fill);                       // fill & ~occ, cg2:566-582
         fill.set(L.wpc - 1, fill.get(L.wpc - 1) & L.lastMask);
         insert_runs(s, d, c, fill, L.Zmax, mat, flags);
