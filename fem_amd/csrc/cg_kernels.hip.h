@@ -484,13 +484,77 @@ __device__ __forceinline__ bool etch_group4(const GridView& g, size_t c0, unsign
     return dirty != 0;
 }
 
+// What the host has verified for one vertical step (thickness t the same for every column), each a licence to replace
+// the double arithmetic of the reference by integer arithmetic on the height steps with the same result:
+//   depo_k >= 0   Math.round((q*zs + t)/zs) == q + depo_k for every q with q + depo_k < 65536 (checked one by one)
+//   etch_kc >= 0  with d = z1q - z0q of the top layer, thick = z1q*zs - z0q*zs in double (within 2e-12 of d*zs):
+//                 d >= etch_kc  <=>  t < thick - 1e-9   (the cut stays inside the layer, cg1:574); the new top is then
+//                                    z1q - etch_ke = Math.round((z1q*zs - t)/zs) (checked for every z1q >= etch_kc);
+//                 d >  etch_kr  <=>  not (t - thick > 1e-9): the layer goes and nothing is left to take (cg1:565);
+//                 d <= etch_kr: the layer goes and the etch continues below with what is left, in double as before.
+//                 Both thresholds were found with a margin of 1e-10 around the reference's 1e-9, fifty times the
+//                 rounding error of thick; a thickness that leaves less gets no licence.
+struct VertOpts { int depo_k, etch_kc, etch_kr, etch_ke; };
+
+__device__ __forceinline__ bool etchable(uint32_t r, int matId, bool isAll);
+
+// depo_group4 for a step whose new heights are q + K (VertOpts::depo_k); a column too tall for that takes the double form.
+__device__ __forceinline__ void depo_group4_int(const GridView& g, size_t c0, unsigned open, int K, double t, int matId, u32x4 tv) {
+    u32x4 nv = tv;
+    unsigned push = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!((open >> j) & 1)) continue;
+        const uint32_t r = tv[j];
+        uint32_t q = rec_z1(r) + (uint32_t)K;
+        if (q > 65535u) q = quantz((double)rec_z1(r) * g.zs + t, g.zs, g.inv_zs);
+        if (r != 0 && rec_mat(r) == matId) nv[j] = rec_with_z1(r, q);
+        else { nv[j] = rec_make_l(q, matId, r != 0 ? g.P : LNK_NONE); if (r != 0) push |= 1u << j; }
+    }
+    if (push) {
+        const size_t b = (size_t)g.P * g.N + c0;
+        if (push == 15u) st_rec4(g.rec + b, tv);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) if ((push >> j) & 1) g.rec[b + j] = tv[j];
+        }
+    }
+    st_rec4(g.top_w + c0, nv);
+}
+
+// etch_group4 for a step with integer thresholds (VertOpts): a cut inside the top layer, or the top layer gone with
+// nothing left to take, are decided on the height steps; columns that go on take the general form.
+__device__ __forceinline__ void etch_group4_int(const GridView& g, size_t c0, unsigned open, const VertOpts& vo, const double (&dz)[4],
+                                                int matId, bool isAll, u32x4 tv) {
+    uint32_t r[4] = {tv[0], tv[1], tv[2], tv[3]}, b[4] = {0, 0, 0, 0};
+    unsigned want = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (((open >> j) & 1) && etchable(r[j], matId, isAll)) want |= 1u << j;
+    if (!want) return;
+    load_below4(g, c0, want, r, b);
+    unsigned general = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (!((want >> j) & 1)) continue;
+        const uint32_t below = rec_lnk(r[j]) != LNK_NONE ? b[j] : 0u;
+        const int d = (int)rec_z1(r[j]) - (int)rec_z1(below);
+        if (d >= vo.etch_kc) { r[j] = rec_with_z1(r[j], rec_z1(r[j]) - (uint32_t)vo.etch_ke); continue; }       // cg1:574-578
+        if (d <= vo.etch_kr) { general |= 1u << j; continue; }
+        r[j] = below;                                                                                         // cg1:579-587, and done
+        if (rec_hole(r[j])) r[j] = rec_lnk(r[j]) == LNK_NONE ? 0u : g.rec[(size_t)rec_lnk(r[j]) * g.N + c0 + j];
+    }
+    if (general) { unsigned nrem = 0; etch_group4_regs<false>(g, c0, general, dz, matId, isAll, r, general, b, nrem); }
+    u32x4 nv; nv[0] = r[0]; nv[1] = r[1]; nv[2] = r[2]; nv[3] = r[3];
+    st_rec4(g.top_w + c0, nv);
+}
+
 // Vertical deposit / etch (fast paths, cg1:445-454 and 609-618).  A thread owns U groups that
 // are 256 groups apart; all their loads are issued before anything is computed or stored.
 // fresh (deposit without a mask only): every column is empty and the tops have not been cleared
 // since the grid was reset -- nothing is loaded, and the launch leaves the stream defined.
-template <bool ETCH, bool STATS, int U>
+template <bool ETCH, bool STATS, int U, bool INT = false>
 __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* __restrict__ mask, int matId, double t, int fresh,
-                                                     int* __restrict__ flags, unsigned long long* gstats) {
+                                                     const VertOpts vo, int* __restrict__ flags, unsigned long long* gstats) {
     unsigned loc[3] = {0, 0, 0};
     const bool isAll = (matId == 255);
     const size_t ngroups = g.N >> 2;
@@ -524,9 +588,15 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
             if (!open[u]) continue;
             const size_t c0 = (gbase + (size_t)u * 256) << 2;
             if (STATS) loc[0] += __popc(open[u]);
-            if (ETCH) { const uint32_t nb[4] = {0, 0, 0, 0};
-                        etch_group4<STATS>(g, c0, open[u], dz, matId, isAll, tv[u], 0u, nb, loc[1], loc[2]); }
-            else depo_group4<STATS>(g, c0, open[u], dz, matId, tv[u], loc[1], loc[2]);
+            // (INT: the host holds the step's integer licence; never together with statistics)
+            if (ETCH) {
+                if (INT) etch_group4_int(g, c0, open[u], vo, dz, matId, isAll, tv[u]);
+                else { const uint32_t nb[4] = {0, 0, 0, 0};
+                       etch_group4<STATS>(g, c0, open[u], dz, matId, isAll, tv[u], 0u, nb, loc[1], loc[2]); }
+            } else {
+                if (INT) depo_group4_int(g, c0, open[u], vo.depo_k, t, matId, tv[u]);
+                else depo_group4<STATS>(g, c0, open[u], dz, matId, tv[u], loc[1], loc[2]);
+            }
         }
     }
     if (STATS) {

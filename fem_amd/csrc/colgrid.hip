@@ -149,6 +149,8 @@ struct cg_grid {
     size_t seed_stride = 0, seed_off = 0; int seed_rows = 0; bool seed_lo = false, seed_hi = false;
     int* d_bbox = nullptr;
     uint8_t* cand = nullptr;                               // strip_connected: columns that still hold an unmarked node
+    struct VOptEntry { double t; bool etch; VertOpts vo; };
+    std::vector<VOptEntry> vopt_cache;                     // integer licences of the last vertical steps (vert_opts)
     AldTap* d_ald_taps = nullptr; int ald_taps_cap = 0;
     std::string err;
 };
@@ -940,9 +942,56 @@ int ald_coat(cg_grid* g, int mat, double t, const uint32_t* hmax_q = nullptr) {
 
 }  // namespace
 
+// The integer licences of a vertical step of thickness t (VertOpts), found by trying: every height step for the
+// quantiser identities, the neighbouring layer thicknesses for the two thresholds.  Kept per handle for the last few
+// thicknesses (a flow repeats them).
+static uint16_t quantz_host(double z, double zs) {
+    const double v = js_round(z / zs);
+    if (!(std::fabs(v) < 9.0e18)) return 0;
+    return (uint16_t)(long long)v;
+}
+
+static VertOpts vert_opts(cg_grid* g, double t, bool etch) {
+    static const bool off = getenv("CG_VERT_NOINT") != nullptr;
+    VertOpts none{-1, -1, -1, -1};
+    if (off || !(t > 0) || !(g->zscale > 1e-6) || !(t / g->zscale < 60000.0)) return none;
+    for (const auto& e : g->vopt_cache) if (e.t == t && e.etch == etch) return e.vo;
+    const double zs = g->zscale, margin = 1e-10;
+    VertOpts vo = none;
+    if (!etch) {
+        const int K = (int)quantz_host(0.0 * zs + t, zs);
+        bool ok = true;
+        for (int q = 0; ok && q + K < 65536; q++) ok = (int)quantz_host((double)q * zs + t, zs) == q + K;
+        if (ok) vo.depo_k = K;
+    } else {
+        // smallest d with t < d*zs - 1e-9, and largest d with t - d*zs > 1e-9, each clear of its boundary by the margin
+        const int d0 = (int)std::floor(t / zs);
+        int kc = -1, kr = -1;
+        bool ok = true;
+        for (int d = std::max(0, d0 - 2); d <= d0 + 3 && ok; d++) {
+            const double x = (double)d * zs;
+            const double a = x - CG_EPS - t;                   // > 0: the cut stays inside a layer d steps thick
+            const double c = t - x - CG_EPS;                   // > 0: something is left to take after such a layer
+            if (std::fabs(a) < margin || std::fabs(c) < margin) ok = false;
+            if (a > 0 && kc < 0) kc = d;
+            if (c > 0) kr = d;
+        }
+        if (d0 - 2 > 0 && kr < 0) ok = false;                  // (the scan must have seen the lower threshold)
+        if (ok && kc >= 1 && kr < kc) {
+            const int ke = kc - (int)quantz_host((double)kc * zs - t, zs);
+            for (int q = kc; ok && q < 65536; q++) ok = (int)quantz_host((double)q * zs - t, zs) == q - ke;
+            if (ok) { vo.etch_kc = kc; vo.etch_kr = kr; vo.etch_ke = ke; }
+        }
+    }
+    if (g->vopt_cache.size() >= 16) g->vopt_cache.erase(g->vopt_cache.begin());
+    g->vopt_cache.push_back({t, etch, vo});
+    return vo;
+}
+
 template <bool ETCH>
 static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, int P) {
     GridView gv = view(g); gv.P = P;
+    const VertOpts vo = g->stats_on ? VertOpts{-1, -1, -1, -1} : vert_opts(g, t, ETCH);
     const int fresh = (!ETCH && g->pristine) ? 1 : 0;
     // groups per thread: 1 for the read-modify-write mixes (measured: appends 0.55 ms, 0.61 with 2 or 4 at 16384^2), 4 for the
     // launch that only writes (the first deposit on a reset grid: 0.36 -> 0.21 ms)
@@ -952,9 +1001,11 @@ static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, 
     size_t nb = (g->N / 4 + (size_t)256 * U - 1) / ((size_t)256 * U);
     if (cap > 0) nb = std::min<size_t>(nb, (size_t)cap);
     const dim3 grid((unsigned)std::max<size_t>(1, std::min<size_t>(nb, 0x7fffffff))), blk(256);
-#define LV(S, UU) hipLaunchKernelGGL((k_vertical_g4<ETCH, S, UU>), grid, blk, 0, g->stream, gv, mask, mat, t, fresh, g->d_flags, g->d_stats)
-    if (g->stats_on) { if (U == 1) LV(true, 1); else if (U == 2) LV(true, 2); else LV(true, 4); }
-    else { if (U == 1) LV(false, 1); else if (U == 2) LV(false, 2); else LV(false, 4); }
+#define LV(S, UU, I) hipLaunchKernelGGL((k_vertical_g4<ETCH, S, UU, I>), grid, blk, 0, g->stream, gv, mask, mat, t, fresh, vo, g->d_flags, g->d_stats)
+    const bool lic = ETCH ? vo.etch_kc >= 0 : vo.depo_k >= 0;
+    if (g->stats_on) { if (U == 1) LV(true, 1, false); else if (U == 2) LV(true, 2, false); else LV(true, 4, false); }
+    else if (lic) { if (U == 1) LV(false, 1, true); else if (U == 2) LV(false, 2, true); else LV(false, 4, true); }
+    else { if (U == 1) LV(false, 1, false); else if (U == 2) LV(false, 2, false); else LV(false, 4, false); }
 #undef LV
     if (fresh) g->pristine = false;          // the tops are defined now; len is behind as after any such launch
 }
