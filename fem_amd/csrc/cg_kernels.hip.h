@@ -1102,6 +1102,35 @@ __device__ __forceinline__ RawGroup stream_load(const GridView& g, const uint8_t
     return o;
 }
 
+// ONE column of a staged row, same rules: the halo columns left and right of a strip are staged one per lane (2 Rp lanes
+// busy), because whatever those few lanes execute the whole wave pays for: as groups of 4 they cost as many
+// instructions per row as the staging of the strip itself.
+struct RawCol { uint32_t a; unsigned m; };
+template <bool ETCH, bool MSG, bool MASKED>
+__device__ __forceinline__ RawCol stream_load1(const GridView& g, const uint8_t* __restrict__ mask, int il, int Rimg, size_t msg_n, int jc, int matId,
+                                               const uint8_t* __restrict__ halo_lo, const uint8_t* __restrict__ halo_up) {
+    RawCol o; o.a = 0; o.m = 0;
+    if (MSG) {
+        const RowSrc src = row_source(g, il, Rimg, halo_lo, halo_up);
+        if (src.msg) {
+            if (src.row >= 0 && src.row < Rimg) {
+                const size_t p = (size_t)src.row * g.ny + jc;
+                o.a = rec_make(((const uint16_t*)src.msg)[p], matId);
+                if (ETCH) o.m = src.msg[2 * msg_n + p];
+            }
+            return o;
+        }
+    }
+    const bool edge = il < 0 || il >= g.nx;
+    const size_t p = (size_t)(il < 0 ? 0 : (il >= g.nx ? g.nx - 1 : il)) * g.ny + jc;
+    o.a = g.top[p];
+    if (ETCH) {
+        if (MASKED) { const unsigned w = mask[p]; o.m = edge ? 0u : w; }
+        else o.m = edge ? 0u : 1u;
+    }
+    return o;
+}
+
 // What the host has verified for this handle and step, each a licence to replace double arithmetic
 // by float arithmetic with the same result:
 //   deq_f32    fmaf(q, zs_hi, q*zs_lo) == float32(double(q)*zscale) for every q < 65536 (checked one by one)
@@ -1138,6 +1167,14 @@ __device__ __forceinline__ float4 stream_heights(const GridView& g, const Stream
     return h;
 }
 
+// the same for one column (beyond: it lies past the first / last column and repeats the edge column, flags zero)
+template <bool ETCH>
+__device__ __forceinline__ float stream_height1(const GridView& g, const StreamOpts& so, const RawCol& w, bool beyond, int matId, bool isAll) {
+    float h = stream_deq(g, so, rec_z1(w.a));
+    if (ETCH && !(!beyond && w.m && etchable(w.a, matId, isAll))) h = __builtin_inff();
+    return h;
+}
+
 // Could entry (du, dv) of the quadrant table lie inside the ellipse of a kernel of radius R?  The
 // ellipse is a circle of radius rho in cells, R <= rho < R+1.  Entries that cannot are skipped at
 // compile time; the others are all evaluated (those outside a particular kernel hold -inf, the
@@ -1154,7 +1191,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
                                                        const uint8_t* __restrict__ halo_lo, const uint8_t* __restrict__ halo_up,
                                                        const float* __restrict__ quad, const StreamOpts so, int* __restrict__ flags, unsigned long long* gstats) {
     using G = StreamGeom<R>;
-    constexpr int Rp = G::Rp, PITCH = G::PITCH, W = G::W, HG = G::HG, TP = STREAM_TAB_PITCH;
+    constexpr int Rp = G::Rp, PITCH = G::PITCH, W = G::W, TP = STREAM_TAB_PITCH;
     __shared__ __align__(16) float s_row[2][PITCH];
     __shared__ __align__(16) float s_tab[(R + 1) * TP];
     // The top records (etch: and mask bytes) of the last R + 2 input rows, as loaded for staging: input row r - R is the
@@ -1183,13 +1220,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
     // this lane's own group (beyond the last column it repeats the edge: it is halo of the lanes before it) ...
     const bool m_right = j0 >= g.ny;
     const int m_jc = m_right ? g.ny - 4 : j0;
-    // ... and, for the first 2 HG lanes, one halo group left or right of the strip
-    const bool has_halo = lane < 2 * HG;
-    const bool h_upper = lane >= HG;
-    const int hj = h_upper ? j_base + STRIP + 4 * (lane - HG) : j_base - Rp + 4 * lane;
-    const bool h_left = hj < 0, h_right = hj >= g.ny;
-    const int h_jc = h_left ? 0 : (h_right ? g.ny - 4 : hj);
-    const int h_at = h_upper ? Rp + STRIP + 4 * (lane - HG) : 4 * lane;
+    // ... and, for the first 2 Rp lanes, one halo column left or right of the strip (the other lanes load the last of
+    // those columns along with them and drop it: a load inside a branch costs a wait for it right there)
+    const bool has_halo = lane < 2 * Rp;
+    const int hl = min(lane, 2 * Rp - 1);
+    const bool h_upper = hl >= Rp;
+    const int hj = h_upper ? j_base + STRIP + (hl - Rp) : j_base - Rp + hl;
+    const bool h_beyond = hj < 0 || hj >= g.ny;
+    const int h_jc = hj < 0 ? 0 : (hj >= g.ny ? g.ny - 1 : hj);
+    const int h_at = h_upper ? STRIP + hl : hl;
 
     float A[2 * R + 1][4];
 #pragma unroll
@@ -1199,15 +1238,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
     // Software pipeline.  While the taps of input row r are evaluated (the long part), the loads of row r+2
     // and of the columns of the next output row are in flight, and the stores of the output row before
     // are draining: the one wait on vector memory in an iteration comes after the taps.
-    RawGroup in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R, Rimg, msg_n, m_jc, matId, halo_lo, halo_up), in_h;
-    in_h.a = (u32x4)(0); in_h.m = 0;
-    if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
+    RawGroup in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);
+    RawCol in_h = stream_load1<ETCH, MSG, MASKED>(g, mask, i_base - R, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
     *(float4*)(s_row[0] + Rp + 4 * lane) = stream_heights<ETCH>(g, so, in_m, false, m_right, matId, isAll);
-    if (has_halo) *(float4*)(s_row[0] + h_at) = stream_heights<ETCH>(g, so, in_h, h_left, h_right, matId, isAll);
+    if (has_halo) s_row[0][h_at] = stream_height1<ETCH>(g, so, in_h, h_beyond, matId, isAll);
     if (RINGED) { *(u32x4*)(s_top[0] + 4 * lane) = in_m.a; if (ETCH) s_msk[0][lane] = in_m.m; }
     if (1 < rows_in) {
         in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + 1, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);
-        if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + 1, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
+        in_h = stream_load1<ETCH, MSG, MASKED>(g, mask, i_base - R + 1, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
     }
 
 #define CG_OP(a, b) __int_as_float(ETCH ? min(__float_as_int(a), __float_as_int(b)) : max(__float_as_int(a), __float_as_int(b)))
@@ -1292,7 +1330,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
         if (r + 1 < rows_in) {
             float* nxt = s_row[(r + 1) & 1];
             *(float4*)(nxt + Rp + 4 * lane) = stream_heights<ETCH>(g, so, in_m, false, m_right, matId, isAll);
-            if (has_halo) *(float4*)(nxt + h_at) = stream_heights<ETCH>(g, so, in_h, h_left, h_right, matId, isAll);
+            asm volatile("" : "+v"(in_h.a), "+v"(in_h.m));      // (looked at from here on: the compiler otherwise starts on it right behind its load, and waits there)
+            if (has_halo) nxt[h_at] = stream_height1<ETCH>(g, so, in_h, h_beyond, matId, isAll);
             if (RINGED) {
                 const int slot = (r + 1) % RING;
                 *(u32x4*)(s_top[slot] + 4 * lane) = in_m.a;
@@ -1305,7 +1344,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
         // waits for its own loads would otherwise wait for these as well.
         if (!(ETCH && FIN) && r + 2 < rows_in) {
             in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);
-            if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
+            in_h = stream_load1<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
         }
         // ---- the update of the output row
         if (FIN && !ETCH) {
@@ -1436,7 +1475,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
         }
         if (ETCH && FIN && r + 2 < rows_in) {
             in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);
-            if (has_halo) in_h = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
+            in_h = stream_load1<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
         }
     };
     for (int r = 0; r < 2 * R; r++) step(r, BoolTag<false>{});
