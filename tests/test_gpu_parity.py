@@ -574,6 +574,39 @@ def test_columns_taller_than_64_intervals():
     g.close()
 
 
+def test_vertical_steps_at_awkward_thicknesses():
+    """Vertical deposits and etches run on integer height steps when the host can vouch for every case of a thickness
+    (statistics off, as here).  Thicknesses at and around the places where that could go wrong -- half a height step,
+    a whole number of steps plus or minus the reference's 1e-9 and fractions of it, a layer etched by exactly its own
+    thickness and a hair more or less -- against the oracle, step by step."""
+    fem = _engine()
+    nx, ny = 48, 64
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    rng = _lcg(4242)
+    red = fem.reduce_mask(_random_mask_data(rng, 2 * nx, 5))
+    gm, om = g.mask_from_shapes(red), o.mask_raster(red)
+    def both(fn, mask, *a):
+        getattr(g, fn)(gm if mask else None, *a); getattr(o, fn)(om if mask else None, *a)
+    e = 1e-9
+    thick = [10.0, 0.05, 0.15, 0.25, 7.25, 7.25 + e, 7.25 - e, 10.0 + e, 10.0 - e, 10.0 + e / 10, 10.0 - e / 10, 10.0 + 2 * e,
+             3.3333333333, 0.1 + e, 0.1 - e, 0.1, 2 * e, e, e / 2, 1e-7, 123.456, 0.30000000000000004, 1.0 / 3.0]
+    k = 0
+    for t in thick:
+        for mask in (False, True):
+            both("deposit_general", mask, 3 + k % 4, t, 0.0); k += 1
+            assert g.checksum() == o.checksum(), f"deposit {t!r} mask={mask}"
+    for t in thick:
+        # a fresh 10 nm layer of material 7 everywhere (20 nm where the mask is open), then the etch under test
+        both("deposit_general", False, 7, 10.0, 0.0)
+        both("deposit_general", True, 7, 10.0, 0.0)
+        for mask, mat in ((True, 7), (False, 255), (False, 7)):
+            both("etch_general", mask, mat, t, 0.0)
+            assert g.checksum() == o.checksum(), f"etch {t!r} mask={mask} mat={mat}"
+    _assert_same(g, o.arrays(), "final")
+    g.close()
+
+
 def test_strip_connected_along_a_serpentine():
     """A buried layer of material 4 that winds through the grid (full rows joined at alternating ends) and is open
     to the air at one end only: the flood has to run the whole path, against and along the sweep direction, over many
