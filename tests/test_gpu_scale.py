@@ -32,8 +32,9 @@ def _masks(fem, flows, g, o, specs, names, n):
     return gm, om
 
 
-@pytest.mark.parametrize("flow_name,n", [("c2", 512), ("c3", 512), ("c4", 1024), ("c5", 384), ("cw", 512)])
-def test_benchmark_flows_vs_oracle(flow_name, n):
+@pytest.mark.parametrize("flow_name,n,stats", [("c2", 512, True), ("c3", 512, True), ("c4", 1024, True), ("c5", 384, True), ("cw", 512, True),
+                                               ("c2", 512, False), ("c3", 768, False), ("c5", 512, False)])
+def test_benchmark_flows_vs_oracle(flow_name, n, stats):
     import fem_amd as fem
     from fem_amd import flows
     flow = flows.FLOWS[flow_name]()
@@ -41,14 +42,14 @@ def test_benchmark_flows_vs_oracle(flow_name, n):
     g = fem.ColumnGrid(2.0 * n, 2.0 * n, 2.0, 2.0)
     o = OracleGrid(2.0 * n, 2.0 * n, 2.0, 2.0)
     gm, om = _masks(fem, flows, g, o, specs, sorted({s["mask"] for s in flow if s["mask"]}), n)
-    g.stats_enable(True)
+    g.stats_enable(stats)      # off: the instantiations a production run uses (no case counts to compare then)
     g.keep_step_snapshots = False
     for k, s in enumerate(flow):
         flows.apply_step(g, s, gm)
         flows.apply_step(o, s, om)
         o.slider_reset()
         assert g.checksum() == o.checksum(), f"{flow_name} step {k} {s}"
-        if s["kind"] in ("SUBSTR", "DEPO", "ETCH"):
+        if stats and s["kind"] in ("SUBSTR", "DEPO", "ETCH"):
             gs, os_ = g.stats(), o.stats()
             assert gs[2:6] == os_[2:6], f"{flow_name} step {k} column counts {gs} vs {os_}"
         if flow_name == "c5":     # C5 extracts cross-sections after every step
