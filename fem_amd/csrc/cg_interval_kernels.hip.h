@@ -592,10 +592,17 @@ __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, con
                     const size_t scl = S.at(s, oi - tp.du, oj - tp.dv);
                     const int n = min((int)seed_n[scl], seed_planes);
                     const BitColShared ob{lds + ((int)threadIdx.x - lane + owner), (int)blockDim.x, L.wpc};
+                    // (the seeds of one column mostly touch one another, and so do their ranges: united like the owner's)
+                    int va = 0, vb = 0; bool vhave = false;
                     for (int q = 1; q < n; q++) {
                         int q0, q1;
-                        if (seed_range(seed[(size_t)q * S.stride + scl], tp, q0, q1)) mark_range_q<false, BitColShared>(ob, q0, q1);
+                        if (!seed_range(seed[(size_t)q * S.stride + scl], tp, q0, q1)) continue;
+                        if ((q1 & 31) == 0) { q1 -= 32; if (q1 <= q0) continue; }
+                        if (vhave && q0 <= vb && q1 >= va) { va = min(va, q0); vb = max(vb, q1); continue; }
+                        if (vhave) mark_range_exact(ob, va, vb);
+                        va = q0; vb = q1; vhave = true;
                     }
+                    if (vhave) mark_range_exact(ob, va, vb);
                 }
             }
             __builtin_amdgcn_wave_barrier();
