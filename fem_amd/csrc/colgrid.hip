@@ -52,7 +52,7 @@ thread_local std::string t_create_error;
 // built for (the reference reuses it as `baseAdd` on a cache hit) and its taps on the device.
 struct ConfKernel {
     int key[4];
-    int Rx;
+    int Rx, Ry = 0;
     double baseAdd;
     std::vector<int> du, dv;
     std::vector<float> add;
@@ -484,7 +484,7 @@ ConfKernel* get_kernel(cg_grid* g, double t, double S) {
     const double dx = g->dx, dy = g->dy;
     const int Rx = (int)std::ceil(t / dx), Ry = (int)std::ceil(t / dy);
     const double t2 = t * t, Sinv = 1 / std::max(S, 1e-6), dx2 = dx * dx, dy2 = dy * dy;
-    k->Rx = Rx; k->baseAdd = t;
+    k->Rx = Rx; k->Ry = Ry; k->baseAdd = t;
     for (int du = -Rx; du <= Rx; du++) {
         const double du2dx2 = (double)du * du * dx2;
         for (int dv = -Ry; dv <= Ry; dv++) {
@@ -524,7 +524,7 @@ int upload_taps(cg_grid* g, ConfKernel* k, int R) {
     int Re = 0;
     for (size_t q = 0; q < k->add.size(); q++) Re = std::max(Re, std::max(std::abs(k->du[q]), std::abs(k->dv[q])));
     k->Re = Re; k->sym_ok = false;
-    if (Re >= 1 && Re <= 8) {
+    if (Re >= 1 && Re <= 8 && g->dx == g->dy) {          // (the quadrant table is read transposed as well: square cells only)
         const int n = Re + 1;
         std::vector<float> quad(n * n, -INFINITY);
         std::vector<int> seen(n * n, 0);
@@ -1379,11 +1379,15 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
         HIPCHK(g, hipGetLastError());
         return CG_OK;
     }
-    if (g->dx != g->dy)
-        return fail(g, CG_ERR_UNSUPPORTED, "lateral steps need dx == dy (the reference pads the height map with Rx in both directions, "
-                                            "script_columngrid.js:471, 666)");
     ConfKernel* K = get_kernel(g, t, S);
     const int R = K->Rx;
+    // The reference pads its height map by Rx cells in BOTH directions (script_columngrid.js:471, 666) while the taps reach
+    // Ry = ceil(t/dy) cells along j.  With Ry <= Rx (any dy >= dx) every tap stays inside the pad and the step is well
+    // defined; with Ry > Rx its reads run into the neighbouring pad row or past the end of a scratch buffer that keeps
+    // what earlier, larger steps left there: nothing a caller could rely on, refused.
+    if (K->Ry > K->Rx)
+        return fail(g, CG_ERR_UNSUPPORTED, "this lateral step reaches %d cells along y but the reference pads its height map by Rx = %d "
+                                            "(script_columngrid.js:471, 666): undefined there when dy < dx", K->Ry, K->Rx);
     // A lateral deposit whose mask opens no column returns before anything changes, identify_cavity
     // included (cg1:474-485; the kernel cache above has its entry by then, cg1:470).  On a slab the
     // question is about the whole domain: the driver asks cg_mask_any_open on every slab.

@@ -160,7 +160,10 @@ int cg_mask_destroy(cg_grid* g, int mask_id);
 /* deposit_general(maskFn, matId, thickness, conformality) (cg1:435-544).
  * t<=0: no-op.  S clamped to [0,1].  t*S < min(dx,dy): vertical deposit on open columns
  * (cg1:445-454).  Otherwise conformal growth by an ellipsoidal max-plus dilation of the
- * top-height map (cg1:457-540) followed by identify_cavity (cg1:543). */
+ * top-height map (cg1:457-540) followed by identify_cavity (cg1:543).
+ * Cells that are not square: the reference pads the height map by Rx = ceil(t/dx) cells in both
+ * directions (cg1:471, 666); a lateral step (deposit or etch) whose taps reach further along y,
+ * ceil(t/dy) > Rx, reads outside that pad there and is refused with CG_ERR_UNSUPPORTED. */
 int cg_deposit_general(cg_grid* g, int mask_id, int mat, double thickness, double conformality);
 
 /* etch_general(maskFn, matId, thickness, conformality) (cg1:598-740); mat 255 = ALL. */

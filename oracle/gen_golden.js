@@ -279,6 +279,26 @@ const etc = (mask, mat, t, S = 0, dump = false) => ({ op: 'etch_general', mask, 
   ]);
 }
 
+// 8b. cells that are not square.  The reference pads its height map by Rx in both directions (cg1:471, 666), so a
+//     lateral step is well defined when the taps reach no further along y than along x: dy > dx (Ry <= Rx), or
+//     dy < dx at thicknesses where the two radii coincide.
+{
+  const masks = {
+    trench: { objects: [rect(0, 0, 300, 300), rect(30, 0, 16, 300, neg), rect(70, 21, 24, 36, neg)] },
+    island: { objects: [rect(0, 0, 300, 300), circle(40, 30, 18, neg)] },
+  };
+  runCase('unequal_pitch', D(120, 90, 2, 3), masks, [
+    dep('all', 3, 30, 0), dep('all', 4, 20, 0), etc('trench', 4, 20, 0), etc('trench', 3, 12, 0, true),
+    dep('all', 5, 10, 1.0, true), etc(null, 5, 6, 1.0, true), dep('island', 6, 7.3, 0.5, true),
+    etc('island', 255, 9, 0.7, true), dep(null, 4, 4, 1.0, true), etc('all', 4, 14, 1.0, true), dep(null, 7, 2.9, 1.0),
+  ]);
+  runCase('unequal_pitch_t', D(120, 90, 3, 2), masks, [
+    dep('all', 3, 30, 0), dep('all', 4, 20, 0), etc('trench', 4, 20, 0), etc('trench', 3, 12, 0, true),
+    dep('all', 5, 4, 1.0, true), etc(null, 5, 2, 1.0, true), dep('island', 6, 3.5, 0.8, true),
+    etc('island', 255, 3.9, 0.6, true), dep(null, 4, 2, 1.0),
+  ]);
+}
+
 // 9. C1 of the benchmark configs through the reference RUNTIME (rt:183-299), 256^2 and 64^2
 for (const NX of [256, 64]) {
   const sc = NX / 256;

@@ -8,7 +8,8 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 STEP_CASES = ["vertical_small", "stencil_small", "stencil_odd", "anchor_256", "masks_small",
-              "growth_small", "cavity_small", "empty_mask_small", "kcache_small", "wet_ald_small", "wet_ald_cache", "wet_ald_thin", "accessors_small"]
+              "growth_small", "cavity_small", "empty_mask_small", "kcache_small", "wet_ald_small", "wet_ald_cache", "wet_ald_thin", "accessors_small",
+              "unequal_pitch", "unequal_pitch_t"]
 
 
 def load_case(name):

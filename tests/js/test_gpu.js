@@ -20,7 +20,7 @@ function fnv(grid) {
 const same = (a, b, what) => { assert.strictEqual(a.length, b.length, what + ' length'); for (let k = 0; k < a.length; k++) if (a[k] !== b[k]) assert.fail(`${what} differs at ${k}: ${a[k]} vs ${b[k]}`); };
 
 for (const name of ['vertical_small', 'stencil_small', 'stencil_odd', 'masks_small', 'growth_small', 'cavity_small', 'kcache_small', 'anchor_256',
-  'wet_ald_small', 'wet_ald_cache', 'wet_ald_thin', 'accessors_small']) {
+  'wet_ald_small', 'wet_ald_cache', 'wet_ald_thin', 'accessors_small', 'unequal_pitch', 'unequal_pitch_t']) {
   const c = JSON.parse(fs.readFileSync(path.join(GOLD, name + '.json')));
   const binPath = path.join(GOLD, name + '.bin.gz');
   const bin = fs.existsSync(binPath) ? zlib.gunzipSync(fs.readFileSync(binPath)) : null;

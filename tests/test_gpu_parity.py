@@ -738,23 +738,47 @@ def test_other_pitches_and_height_steps(dx, zs, lmax):
     g.close()
 
 
-def test_unequal_pitch_vertical_only():
-    """dx != dy: vertical steps match the oracle; lateral steps are refused (the reference pads its
-    height map with Rx in both directions there, script_columngrid.js:471, 666)."""
+def test_unequal_pitch():
+    """dx != dy.  Vertical steps match the oracle for any pitch.  Lateral steps: the reference pads its height map by
+    Rx cells in both directions (script_columngrid.js:471, 666), so they are well defined while the taps reach no
+    further along y than along x (Ry <= Rx: any dy > dx; dy < dx only at thicknesses where the radii coincide) and
+    match the oracle there (the fixtures unequal_pitch / unequal_pitch_t pin the same against the reference); a step
+    with Ry > Rx reads outside the pad in the reference and is refused, leaving the grid as it was."""
     fem = _engine()
     g = fem.ColumnGrid(120, 90, 2.0, 3.0)
     o = OracleGrid(120, 90, 2.0, 3.0)
     assert (g.NX, g.NY) == (o.NX, o.NY) == (60, 30)
+    rng = _lcg(77)
+    red = fem.reduce_mask(_random_mask_data(rng, 90, 6))
+    gm, om = g.mask_from_shapes(red), o.mask_raster(red)
+    np.testing.assert_array_equal(gm.download(), om)
     for mat, t in ((3, 10), (4, 6.5), (3, 2)):
         g.deposit_general(None, mat, t, 0); o.deposit_general(None, mat, t, 0)
-    g.etch_general(None, 255, 4.4, 0); o.etch_general(None, 255, 4.4, 0)
+    g.etch_general(gm, 255, 4.4, 0); o.etch_general(om, 255, 4.4, 0)
     g.deposit_general(None, 5, 1.9, 1.0); o.deposit_general(None, 5, 1.9, 1.0)     # t*S < min(dx, dy): still vertical
     assert g.checksum() == o.checksum()
+    for k, (kind, m, mat, t, S) in enumerate([("d", None, 5, 8, 1.0), ("e", None, 5, 8, 1.0), ("d", True, 6, 13.3, 0.6), ("e", True, 255, 9.1, 0.9),
+                                              ("d", None, 7, 41, 1.0), ("e", None, 7, 23, 0.5)]):
+        for grid, mask in ((g, gm), (o, om)):
+            (grid.deposit_general if kind == "d" else grid.etch_general)(mask if m else None, mat, t, S)
+        assert g.checksum() == o.checksum(), f"lateral step {k}"
+    _assert_same(g, o.arrays(), "dx 2, dy 3")
+    g.close()
+    # dy < dx: fine while ceil(t/dy) == ceil(t/dx), refused beyond
+    g = fem.ColumnGrid(120, 90, 3.0, 2.0)
+    o = OracleGrid(120, 90, 3.0, 2.0)
+    for mat, t in ((3, 10), (4, 6.5)):
+        g.deposit_general(None, mat, t, 0); o.deposit_general(None, mat, t, 0)
+    g.deposit_general(None, 5, 4, 1.0); o.deposit_general(None, 5, 4, 1.0)         # Rx = Ry = 2
+    g.etch_general(None, 5, 2, 1.0); o.etch_general(None, 5, 2, 1.0)               # Rx = Ry = 1
+    assert g.checksum() == o.checksum()
     with pytest.raises(fem.ColGridError):
-        g.deposit_general(None, 5, 8, 1.0)
+        g.deposit_general(None, 5, 8, 1.0)                                         # Rx = 3, Ry = 4
     with pytest.raises(fem.ColGridError):
         g.etch_general(None, 5, 8, 1.0)
     assert g.checksum() == o.checksum()
+    g.deposit_general(None, 6, 3.5, 0.8); o.deposit_general(None, 6, 3.5, 0.8)     # the handle still works
+    _assert_same(g, o.arrays(), "dx 3, dy 2")
     g.close()
 
 

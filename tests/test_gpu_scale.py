@@ -191,8 +191,8 @@ def test_edge_cases():
     g.close()
     with pytest.raises(fem.ColGridError):
         fem.ColumnGrid(10, 10, 0, 2)                 # bad pitch
-    g = fem.ColumnGrid(20, 20, 2, 4)                 # dx != dy: vertical steps fine, lateral ones refused
+    g = fem.ColumnGrid(20, 20, 4, 2)                 # dy < dx: a lateral step that reaches further along y than along x is refused
     g.deposit_general(None, 3, 10, 0)
     with pytest.raises(fem.ColGridError):
-        g.deposit_general(None, 4, 10, 1.0)
+        g.deposit_general(None, 4, 10, 1.0)          # Rx = 3, Ry = 5
     g.close()
