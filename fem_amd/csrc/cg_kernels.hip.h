@@ -1138,7 +1138,9 @@ __device__ __forceinline__ RawCol stream_load1(const GridView& g, const uint8_t*
 //              start value float32(H + t) (cg1:499) is then the centre tap's candidate and need not be made
 //   grow_f32   zscale is large enough that two different float32 heights differ by more than the
 //              reference's 1e-9: "Hp - H > 1e-9" (cg1:537) is then "Hp > H" on the float32 values
-struct StreamOpts { float zs_hi, zs_lo, izf; int deq_f32, skip_init, grow_f32; };
+//   a00        the centre increment of the table (a float32-exact tap, or this kernel is not used)
+//   fast_rows  etch: the rows of a tile are first tried without their neighbours (stream_etch_fast_rows)
+struct StreamOpts { float zs_hi, zs_lo, izf; int deq_f32, skip_init, grow_f32; float a00; int fast_rows; };
 
 __device__ __forceinline__ float stream_deq(const GridView& g, const StreamOpts& o, unsigned q) {
     if (o.deq_f32) { const float qf = (float)q; return __builtin_fmaf(qf, o.zs_hi, qf * o.zs_lo); }
@@ -1175,6 +1177,132 @@ __device__ __forceinline__ float stream_height1(const GridView& g, const StreamO
     return h;
 }
 
+// min of two floats as integers on their bit patterns: right for non-negative numbers and +inf; with a negative operand it
+// returns SOME negative number, which is all its users need (they clamp at 0 right after: cg1:725).
+__device__ __forceinline__ float stream_min_bits(float a, float b) { return __int_as_float(min(__float_as_int(a), __float_as_int(b))); }
+
+// The isotropic etch's update of 4 columns of an output row: A0 = the eroded height from the taps (cg1:704-722), tv = the
+// columns' top records, b4 = the records below them, act = the columns that are open and etchable.
+__device__ __forceinline__ void stream_etch_update(const GridView& g, const StreamOpts& so, const size_t c0, const u32x4 tv, const unsigned act,
+                                                   const uint32_t (&b4)[4], const float (&A0)[4], const int matId, const bool isAll, const double t,
+                                                   const bool m_right, unsigned (&loc)[4]) {
+    // _applyEtchAt (cg1:553-589) by dz = H - Hp (cg1:730-739) on 4 columns.  The usual outcomes -- a cut inside the
+    // top layer, or the top layer going as a whole with nothing more to take below -- are decided here, in float
+    // arithmetic where that provably gives the reference's numbers and otherwise by the reference's own double
+    // expressions; a column that goes on into further layers, rests on a gap, or whose floor lies below the
+    // layer under it takes the general form (etch_group4_regs).
+    uint32_t rn[4] = {tv[0], tv[1], tv[2], tv[3]};
+    double dzs[4] = {0, 0, 0, 0};
+    unsigned walk = 0, general = 0, changed = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (!((act >> c) & 1)) continue;
+        const uint32_t rc = tv[c], b = b4[c];
+        const bool has_b = rec_lnk(rc) != LNK_NONE;
+        const unsigned q1 = rec_z1(rc), bq = has_b ? rec_z1(b) : 0u;
+        if (has_b && (rec_hole(b) || (!isAll && rec_mat(b) == matId))) { walk |= 1u << c; continue; }     // floor and cut need a look further down
+        const float own = stream_deq(g, so, q1), bottom = stream_deq(g, so, bq);
+        float m = A0[c];
+        if (!so.skip_init) m = stream_min_bits(m, (float)((double)own - t));                                       // cg1:702
+        const float hpv = fmaxf(0.f, fmaxf(isAll ? 0.f : bottom, m));                                    // cg1:725 (the floor is the layer's own bottom)
+        const bool cut = so.grow_f32 ? own > hpv : (double)own - (double)hpv > CG_EPS;                    // cg1:731-733
+        if (!cut) continue;
+        // cg1:574: the cut stays inside the top layer iff remaining < thick - 1e-9, remaining = H - Hp, thick = z1 - z0.
+        // H and `bottom` are the float32 of z1 and z0 (off by <= 2^-24 of them), so remaining - thick = -(Hp - bottom) + e,
+        // |e| < 6e-8 (H + bottom): a gap of twice that and 1e-8 decides it; closer calls use the double expressions.
+        bool partial = (hpv - bottom) > ((own + bottom) * 1.3e-7f + 1.0e-8f) * 1.01f;
+        double rem = 0;
+        if (!partial) {
+            rem = (double)own - (double)hpv;
+            const double thick = (double)q1 * g.zs - (double)bq * g.zs;
+            partial = rem < thick - CG_EPS;
+            if (!partial) {                                                                               // the layer goes (cg1:579-587)
+                const double rest = rem - thick;
+                if (has_b && rest > CG_EPS && (isAll || rec_mat(b) == matId)) { dzs[c] = rem; general |= 1u << c; continue; }
+                rn[c] = has_b ? b : 0u; changed |= 1u << c;
+                continue;
+            }
+        }
+        // new top of the cut layer: Math.round((z1 - remaining)/zs) = round((Hp - e1)/zs), as in the deposit update
+        const float y = hpv * so.izf, rr = __builtin_rintf(y);
+        unsigned qn = (unsigned)(int)rr;
+        if (!(__builtin_fabsf(y - rr) < 0.5f - (y * 1.4e-7f + (float)q1 * 6.2e-8f + 2e-6f)) || !(y < 1.0e6f))
+            qn = quantz((double)q1 * g.zs - ((double)own - (double)hpv), g.zs, g.inv_zs);
+        rn[c] = rec_with_z1(rc, qn); changed |= 1u << c;
+    }
+    if (walk) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (!((walk >> c) & 1)) continue;
+            const float own = stream_deq(g, so, rec_z1(tv[c]));
+            const float m = stream_min_bits(A0[c], (float)((double)own - t));
+            float F = 0.f;                                           // floor = bottom of the top run of matId (cg1:646-660)
+            if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, matId, tv[c], b4[c], loc[3]));
+            const float hpv = fmaxf(0.f, fmaxf(F, m));
+            const double d = (double)own - (double)hpv;
+            if (d > CG_EPS) { dzs[c] = d; general |= 1u << c; }
+        }
+    }
+    if (general) changed |= etch_group4_regs<false>(g, c0, general, dzs, matId, isAll, rn, act, b4, loc[2]);
+    if (!m_right && (changed || g.top_w != g.top)) {
+        u32x4 nv; nv[0] = rn[0]; nv[1] = rn[1]; nv[2] = rn[2]; nv[3] = rn[3];
+        st_rec4(g.top_w + c0, nv);
+    }
+}
+
+// An etchable column whose own candidate H - t (cg1:702, and the centre tap) already lies at or below its floor ends at
+// max(0, floor) whatever its neighbours are: cg1:725 takes the maximum of floor and eroded height, and neighbours can only
+// lower the latter.  That is the usual case wherever a step takes off a whole film with some over-etch.  A tile
+// therefore starts without the stencil: its output rows are updated from their own columns alone, one after the other, for
+// as long as no open column of the row could end above its floor; from the first row where one could, the streaming form
+// takes over.  Returns the number of rows done.  Three rows are in flight: the tops of row o+2 and the records below the
+// tops of row o+1 are requested before row o is looked at (rows past the tile's last repeat it).  (Chunks of four rows
+// with two chunks in flight were no faster, and their registers cost the small radii a wave per SIMD.)
+template <bool MASKED>
+__device__ __forceinline__ int stream_etch_fast_rows(const GridView& g, const uint8_t* __restrict__ mask, const StreamOpts& so, const int i_base,
+                                                     const int rows_out, const int m_jc, const bool m_right, const int matId, const bool isAll,
+                                                     const double t, unsigned (&loc)[4]) {
+    const int last = rows_out - 1;
+    const auto col0 = [&](int o) { return (size_t)(i_base + min(o, last)) * g.ny + m_jc; };
+    u32x4 tvA = ld_rec4(g.top + col0(0)), tvB = ld_rec4(g.top + col0(1));
+    unsigned mkA = 0x01010101u, mkB = 0x01010101u;
+    if (MASKED) { mkA = *(const unsigned*)(mask + col0(0)); mkB = *(const unsigned*)(mask + col0(1)); }
+    uint32_t bA[4], bB[4];
+    load_below4_flat(g, col0(0), tvA, bA);
+    int o = 0;
+    for (; o < rows_out; o++) {
+        const u32x4 tvC = ld_rec4(g.top + col0(o + 2));
+        unsigned mkC = 0x01010101u;
+        if (MASKED) mkC = *(const unsigned*)(mask + col0(o + 2));
+        load_below4_flat(g, col0(o + 1), tvB, bB);
+        // ---- row o
+        unsigned act = ((mkA & 0xffu) ? 1u : 0u) | ((mkA & 0xff00u) ? 2u : 0u) | ((mkA & 0xff0000u) ? 4u : 0u) | ((mkA & 0xff000000u) ? 8u : 0u);
+#pragma unroll
+        for (int c = 0; c < 4; c++) if (!etchable(tvA[c], matId, isAll)) act &= ~(1u << c);
+        if (m_right) act = 0;
+        float A0[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned need = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (!((act >> c) & 1)) continue;
+            const uint32_t rc = tvA[c], b = bA[c];
+            const bool has_b = rec_lnk(rc) != LNK_NONE;
+            if (has_b && (rec_hole(b) || (!isAll && rec_mat(b) == matId))) { need |= 1u << c; continue; }      // the floor lies further down
+            const float own = stream_deq(g, so, rec_z1(rc)), bottom = stream_deq(g, so, has_b ? rec_z1(b) : 0u);
+            float m = own - so.a00;                                                                            // the centre tap (cg1:719)
+            A0[c] = m;
+            if (!so.skip_init) m = stream_min_bits(m, (float)((double)own - t));                               // cg1:702
+            if (m > fmaxf(0.f, isAll ? 0.f : bottom)) need |= 1u << c;
+        }
+        if (__builtin_amdgcn_ballot_w64(need != 0) != 0) break;
+        stream_etch_update(g, so, col0(o), tvA, act, bA, A0, matId, isAll, t, m_right, loc);
+        tvA = tvB; mkA = mkB; tvB = tvC; mkB = mkC;
+#pragma unroll
+        for (int c = 0; c < 4; c++) bA[c] = bB[c];
+    }
+    return o;
+}
+
 // Could entry (du, dv) of the quadrant table lie inside the ellipse of a kernel of radius R?  The
 // ellipse is a circle of radius rho in cells, R <= rho < R+1.  Entries that cannot are skipped at
 // compile time; the others are all evaluated (those outside a particular kernel hold -inf, the
@@ -1206,9 +1334,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
     const int tiles_j = (g.ny + STRIP - 1) / STRIP;
     int tile_i, tile_j;
     if (!tile_of_block(g, tiles_j, tile_i, tile_j)) return;
-    const int i_base = tile_i * g.ti, j_base = tile_j * STRIP;
-    const int rows_out = min(g.ti, g.nx - i_base);
-    const int rows_in = rows_out + 2 * R;
+    int i_base = tile_i * g.ti, rows_out = min(g.ti, g.nx - i_base);
+    const int j_base = tile_j * STRIP;
     const int lane = threadIdx.x;
     const int j0 = j_base + 4 * lane;
     const bool isAll = (matId == 255);
@@ -1229,11 +1356,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
     const bool h_beyond = hj < 0 || hj >= g.ny;
     const int h_jc = hj < 0 ? 0 : (hj >= g.ny ? g.ny - 1 : hj);
     const int h_at = h_upper ? STRIP + hl : hl;
+    unsigned loc[4] = {0, 0, 0, 0};      // (statistics are not kept by this form: with them enabled the host runs k_stencil_sym)
+
+    if (ETCH && so.fast_rows) {          // the rows at the head of the tile that need no neighbours
+        const int done = stream_etch_fast_rows<MASKED>(g, mask, so, i_base, rows_out, m_jc, m_right, matId, isAll, t, loc);
+        if (done == rows_out) return;
+        i_base += done; rows_out -= done;
+    }
+    const int rows_in = rows_out + 2 * R;
 
     float A[2 * R + 1][4];
 #pragma unroll
     for (int k = 0; k <= 2 * R; k++) { A[k][0] = 0.f; A[k][1] = 0.f; A[k][2] = 0.f; A[k][3] = 0.f; }
-    unsigned loc[4] = {0, 0, 0, 0};      // (statistics are not kept by this form: with them enabled the host runs k_stencil_sym)
 
     // Software pipeline.  While the taps of input row r are evaluated (the long part), the loads of row r+2
     // and of the columns of the next output row are in flight, and the stores of the output row before
@@ -1409,70 +1543,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
             }
             if (!stored && !m_right && g.top_w != g.top) st_rec4(g.top_w + c0, tv);          // columns that stay as they are
         }
-        if (FIN && ETCH) {
-            // _applyEtchAt (cg1:553-589) by dz = H - Hp (cg1:730-739) on 4 columns.  The usual outcomes -- a cut inside the
-            // top layer, or the top layer going as a whole with nothing more to take below -- are decided here, in float
-            // arithmetic where that provably gives the reference's numbers and otherwise by the reference's own double
-            // expressions; a column that goes on into further layers, rests on a gap, or whose floor lies below the
-            // layer under it takes the general form (etch_group4_regs).
-            uint32_t rn[4] = {tv[0], tv[1], tv[2], tv[3]};
-            double dzs[4] = {0, 0, 0, 0};
-            unsigned walk = 0, general = 0, changed = 0;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (!((act >> c) & 1)) continue;
-                const uint32_t rc = tv[c], b = b4[c];
-                const bool has_b = rec_lnk(rc) != LNK_NONE;
-                const unsigned q1 = rec_z1(rc), bq = has_b ? rec_z1(b) : 0u;
-                if (has_b && (rec_hole(b) || (!isAll && rec_mat(b) == matId))) { walk |= 1u << c; continue; }     // floor and cut need a look further down
-                const float own = stream_deq(g, so, q1), bottom = stream_deq(g, so, bq);
-                float m = A[0][c];
-                if (!so.skip_init) m = CG_OP(m, (float)((double)own - t));                                       // cg1:702
-                const float hpv = fmaxf(0.f, fmaxf(isAll ? 0.f : bottom, m));                                    // cg1:725 (the floor is the layer's own bottom)
-                const bool cut = so.grow_f32 ? own > hpv : (double)own - (double)hpv > CG_EPS;                    // cg1:731-733
-                if (!cut) continue;
-                // cg1:574: the cut stays inside the top layer iff remaining < thick - 1e-9, remaining = H - Hp, thick = z1 - z0.
-                // H and `bottom` are the float32 of z1 and z0 (off by <= 2^-24 of them), so remaining - thick = -(Hp - bottom) + e,
-                // |e| < 6e-8 (H + bottom): a gap of twice that and 1e-8 decides it; closer calls use the double expressions.
-                bool partial = (hpv - bottom) > ((own + bottom) * 1.3e-7f + 1.0e-8f) * 1.01f;
-                double rem = 0;
-                if (!partial) {
-                    rem = (double)own - (double)hpv;
-                    const double thick = (double)q1 * g.zs - (double)bq * g.zs;
-                    partial = rem < thick - CG_EPS;
-                    if (!partial) {                                                                               // the layer goes (cg1:579-587)
-                        const double rest = rem - thick;
-                        if (has_b && rest > CG_EPS && (isAll || rec_mat(b) == matId)) { dzs[c] = rem; general |= 1u << c; continue; }
-                        rn[c] = has_b ? b : 0u; changed |= 1u << c;
-                        continue;
-                    }
-                }
-                // new top of the cut layer: Math.round((z1 - remaining)/zs) = round((Hp - e1)/zs), as in the deposit update
-                const float y = hpv * so.izf, rr = __builtin_rintf(y);
-                unsigned qn = (unsigned)(int)rr;
-                if (!(__builtin_fabsf(y - rr) < 0.5f - (y * 1.4e-7f + (float)q1 * 6.2e-8f + 2e-6f)) || !(y < 1.0e6f))
-                    qn = quantz((double)q1 * g.zs - ((double)own - (double)hpv), g.zs, g.inv_zs);
-                rn[c] = rec_with_z1(rc, qn); changed |= 1u << c;
-            }
-            if (walk) {
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    if (!((walk >> c) & 1)) continue;
-                    const float own = stream_deq(g, so, rec_z1(tv[c]));
-                    const float m = CG_OP(A[0][c], (float)((double)own - t));
-                    float F = 0.f;                                           // floor = bottom of the top run of matId (cg1:646-660)
-                    if (!isAll) F = (float)fmax(0.0, floor_of_top_run(g, c0 + c, matId, tv[c], b4[c], loc[3]));
-                    const float hpv = fmaxf(0.f, fmaxf(F, m));
-                    const double d = (double)own - (double)hpv;
-                    if (d > CG_EPS) { dzs[c] = d; general |= 1u << c; }
-                }
-            }
-            if (general) changed |= etch_group4_regs<false>(g, c0, general, dzs, matId, isAll, rn, act, b4, loc[2]);
-            if (!m_right && (changed || g.top_w != g.top)) {
-                u32x4 nv; nv[0] = rn[0]; nv[1] = rn[1]; nv[2] = rn[2]; nv[3] = rn[3];
-                st_rec4(g.top_w + c0, nv);
-            }
-        }
+        if (FIN && ETCH) stream_etch_update(g, so, c0, tv, act, b4, A[0], matId, isAll, t, m_right, loc);
         if (ETCH && FIN && r + 2 < rows_in) {
             in_m = stream_load<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, m_jc, matId, halo_lo, halo_up);
             in_h = stream_load1<ETCH, MSG, MASKED>(g, mask, i_base - R + r + 2, Rimg, msg_n, h_jc, matId, halo_lo, halo_up);
@@ -1858,7 +1929,11 @@ __global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh, int ma
 // direction it runs, and the host alternates the direction (reverse: from the last column down) until a sweep changes
 // nothing.  (Relaxing a tile to its own fixpoint inside one launch was tried: lanes of a wave run in step, a mark moves
 // one column per pass along a row, and the tiles that do change cost up to a tile's width in passes: 2x slower overall.)
-__global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand, int reverse, int* __restrict__ changed) {
+// before: the flag word of the sweep launched just before this one on the same stream, or null.  A sweep that changed
+// nothing has found the fixpoint, so the sweeps queued behind it in the same batch return at once.
+__global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand, int reverse, int* __restrict__ changed,
+                                                     const int* __restrict__ before) {
+    if (before && __hip_atomic_load(before, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     int any = 0;
     for (size_t cc = (size_t)blockIdx.x * blockDim.x + threadIdx.x; cc < g.N; cc += stride) {

@@ -701,6 +701,8 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
         StreamOpts sopt = g->sopt;
         sopt.skip_init = ((double)(float)t_eff == t_eff && !K->quad.empty() && K->quad[0] == (float)t_eff) ? 1 : 0;
         if (getenv("CG_STREAM_NOF32")) { sopt.deq_f32 = 0; sopt.skip_init = 0; sopt.grow_f32 = 0; }
+        sopt.a00 = K->quad.empty() ? 0.f : K->quad[0];
+        sopt.fast_rows = (etch && !K->quad.empty() && K->quad[0] != -INFINITY && !getenv("CG_STREAM_NOFAST")) ? 1 : 0;
 #define STREAM_L(RR, E, M, K_, BAND)                                                                           \
     do {                                                                                                       \
         gv.tile_i0 = (BAND).t0; gv.tile_in = (BAND).n; gv.sup_i = 1; gv.sup_j = 1;                             \
@@ -1642,7 +1644,8 @@ int cg_strip_sweep(cg_grid* g, int mat, int planes, const void* ghost_lower, con
         if (round > 1000000) return fail(g, CG_ERR_STATE, "strip_connected did not converge");
         HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
         for (int sweep = 0; sweep < 4; sweep++)
-            hipLaunchKernelGGL(k_strip_flood, grid, blk, 0, g->stream, view(g), gh, mat, g->cand, sweep & 1, g->d_flags + sweep);
+            hipLaunchKernelGGL(k_strip_flood, grid, blk, 0, g->stream, view(g), gh, mat, g->cand, sweep & 1, g->d_flags + sweep,
+                               sweep > 0 ? g->d_flags + sweep - 1 : nullptr);
         HIPCHK(g, hipGetLastError());
         int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
         if (fl[0] || fl[1] || fl[2] || fl[3]) any = 1;

@@ -738,6 +738,34 @@ def test_other_pitches_and_height_steps(dx, zs, lmax):
     g.close()
 
 
+@pytest.mark.parametrize("t_etch,S", [(12.0, 1.0), (10.0, 1.0), (16.4, 0.5)])
+def test_isotropic_overetch_rows_without_neighbours(t_etch, S):
+    """An isotropic etch deeper than the film it takes off: the streaming lateral kernel updates the rows at the head of
+    a tile from their own columns alone (the result is the floor whatever the neighbours are, script_columngrid.js:725)
+    and switches to the stencil at the first row where a column could end above its floor -- here the band of rows with a
+    thicker film, which starts in the middle of a tile.  With t equal to the film's thickness the float32 candidates
+    land on either side of the floor and the stencil decides, as in the reference.  Against the oracle, full arrays."""
+    fem = _engine()
+    nx, ny = 200, 520
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    band = np.zeros((nx, ny), np.uint8); band[90:121, 40:400] = 1
+    holes = np.ones((nx, ny), np.uint8); holes[10:30, 100:130] = 0; holes[150:160, :] = 0
+    gm_band, gm_holes = g.mask_from_raster(band.reshape(-1)), g.mask_from_raster(holes.reshape(-1))
+    for grid, mb, mh in ((g, gm_band, gm_holes), (o, band.reshape(-1), holes.reshape(-1))):
+        grid.deposit_general(None, 3, 30.3, 0)
+        grid.deposit_general(None, 5, 10, 0)
+        grid.deposit_general(mb, 5, 8, 0)                  # the film is 18 nm thick in the band
+        grid.etch_general(mh, 5, t_etch, S)                # masked: rows 150..159 closed, a closed patch
+    _assert_same(g, o.arrays(), "masked over-etch")
+    for grid in (g, o):
+        grid.deposit_general(None, 4, 7.7, 0)
+        grid.etch_general(None, 255, t_etch, S)            # ALL: the floor is 0, nothing ends there
+        grid.etch_general(None, 3, 50, 0.3)                # takes the whole substrate off wherever it is on top
+    _assert_same(g, o.arrays(), "ALL and substrate")
+    g.close()
+
+
 def test_unequal_pitch():
     """dx != dy.  Vertical steps match the oracle for any pitch.  Lateral steps: the reference pads its height map by
     Rx cells in both directions (script_columngrid.js:471, 666), so they are well defined while the taps reach no
