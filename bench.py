@@ -244,11 +244,35 @@ def main():
             if s["kind"] in ("SUBSTR", "DEPO"):
                 return "k_stencil<deposit>" if stencil else "k_vertical_g4<deposit>"
             return "k_stencil<etch>" if stencil else "k_vertical_g4<etch>"
-        kbytes = {}
+        # Consecutive vertical steps go out as ONE launch (k_vertical_fused, up to FUSE_MAX steps): the library queues
+        # them until something else wants the grid -- a lateral step, createNewGrid at the wrap of the flow, the
+        # cross-sections of C5, the end of the timed region.  The same rule here says which launch a step's bytes belong to.
+        FUSE_MAX = 6
+        fusing = not os.environ.get("CG_NO_FUSE")
+        kbytes, run, fused_launches, fused_steps = {}, [], 0, 0
+
+        def close_run():
+            nonlocal fused_launches, fused_steps
+            if len(run) >= 2:
+                kbytes["k_vertical_fused"] = kbytes.get("k_vertical_fused", 0) + sum(step_bytes[i] for i in run)
+                fused_launches += 1; fused_steps += len(run)
+            elif run:
+                kd1 = kind_of(flow[run[0]])
+                kbytes[kd1] = kbytes.get(kd1, 0) + step_bytes[run[0]]
+            run.clear()
         for q in range(args.steps):
             idx = (k + q) % len(flow)
             kd = kind_of(flow[idx])
-            kbytes[kd] = kbytes.get(kd, 0) + step_bytes[idx]
+            if idx == 0:
+                close_run()
+            if kd.startswith("k_vertical") and fusing:
+                run.append(idx)
+                if len(run) == FUSE_MAX or slice_idx:
+                    close_run()
+            else:
+                close_run()
+                kbytes[kd] = kbytes.get(kd, 0) + step_bytes[idx]
+        close_run()
         kernels = {}
         for name, (ms, cnt) in prof.items():
             kernels[name] = {"ms_total": round(ms, 4), "launches": cnt, "ms_avg": round(ms / cnt, 4)}
@@ -287,6 +311,9 @@ def main():
             "halo": {"bytes_sent_per_rank": halo_b, "bytes_per_step": round(halo_b / max(1, args.steps), 1),
                      "exchange_ms_total": round(swap_s * 1e3, 3)},
             "whole_flow_algorithmic_GBps": round(total_alg * world / 1e9 / dt, 1),
+            "fusion": {"vertical_steps_fused": fused_steps, "fused_launches": fused_launches,
+                       "note": "runs of consecutive vertical steps are applied in one pass over the columns (k_vertical_fused); "
+                               "its algorithmic bytes are the sum of its steps', so its GB/s is not an HBM rate; CG_NO_FUSE=1 launches every step on its own"},
             "checksum": "%016x" % check,
             "roofline": roofline, "kernels": kernels,
         }

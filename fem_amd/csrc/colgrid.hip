@@ -26,7 +26,7 @@ static int vu_setting() {
     return v;
 }
 template <bool ETCH>
-static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, int P);
+static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, int P, bool fresh_grid);
 // columns per tile row of the symmetric stencil kernel: 128 for the memory-bound radii, 64 above
 // (measured: -5 % at R <= 2, +6 % at R = 7 for 128); env CG_TJS = 64, 128, 256 overrides
 static int sym_tile_cols(int Re) {
@@ -149,6 +149,10 @@ struct cg_grid {
     size_t seed_stride = 0, seed_off = 0; int seed_rows = 0; bool seed_lo = false, seed_hi = false;
     int* d_bbox = nullptr;
     uint8_t* cand = nullptr;                               // strip_connected: columns that still hold an unmarked node
+    // vertical steps queued for one fused launch (see k_vertical_fused): nothing has looked at the grid since the first
+    struct VQOp { const uint8_t* mask; bool etch; int mat; double t; int P; bool fresh; };
+    std::vector<VQOp> vq;
+    bool fuse = true;                                      // CG_NO_FUSE=1: every vertical step is launched on its own
     struct VOptEntry { double t; bool etch; VertOpts vo; };
     std::vector<VOptEntry> vopt_cache;                     // integer licences of the last vertical steps (vert_opts)
     AldTap* d_ald_taps = nullptr; int ald_taps_cap = 0;
@@ -188,10 +192,14 @@ struct ProfScope {
     } while (0)
 
 int materialize(cg_grid* g);
-#define NEED_H(g)                                                                             \
+int flush_vertical(cg_grid* g);
+#define NEED_H0(g)                                                                            \
     do { if (!(g)) return fail(nullptr, CG_ERR_ARG, "null handle");                           \
          hipError_t e__ = hipSetDevice((g)->device);                                          \
          if (e__ != hipSuccess) return fail(g, CG_ERR_HIP, "hipSetDevice(%d): %s", (g)->device, hipGetErrorString(e__)); } while (0)
+// every entry point but the one that queues vertical steps first launches what is queued
+#define NEED_H(g)                                                                             \
+    do { NEED_H0(g); if (!(g)->vq.empty()) { int rcf__ = flush_vertical(g); if (rcf__) return rcf__; } } while (0)
 // entry points that read or write the columns: a grid that was reset but whose streams have not
 // been cleared yet (see zero_planes) is cleared first
 #define NEED(g)                                                                               \
@@ -618,7 +626,7 @@ int run_depo_vertical(cg_grid* g, const uint8_t* mask, int mat, double t) {
     GridView gv = view(g); gv.P = P;
     if (g->split && g->N % 4 == 0 && !may_overflow) {        // 4 columns per thread, no look at the lengths
         ProfScope ps(g, CG_K_DEPO_VERTICAL);
-        launch_vertical<false>(g, mask, mat, t, P);
+        launch_vertical<false>(g, mask, mat, t, P, g->pristine);
         HIPCHK(g, hipGetLastError());
         g->len_valid = false;
     } else {
@@ -991,10 +999,10 @@ static VertOpts vert_opts(cg_grid* g, double t, bool etch) {
 }
 
 template <bool ETCH>
-static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, int P) {
+static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, int P, bool fresh_grid) {
     GridView gv = view(g); gv.P = P;
     const VertOpts vo = g->stats_on ? VertOpts{-1, -1, -1, -1} : vert_opts(g, t, ETCH);
-    const int fresh = (!ETCH && g->pristine) ? 1 : 0;
+    const int fresh = (!ETCH && fresh_grid) ? 1 : 0;
     // groups per thread: 1 for the read-modify-write mixes (measured: appends 0.55 ms, 0.61 with 2 or 4 at 16384^2), 4 for the
     // launch that only writes (the first deposit on a reset grid: 0.36 -> 0.21 ms)
     const int U = getenv("CG_VU") ? vu_setting() : (fresh ? 4 : 1);
@@ -1012,6 +1020,85 @@ static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, 
     if (fresh) g->pristine = false;          // the tops are defined now; len is behind as after any such launch
 }
 
+// ---- runs of vertical steps ---------------------------------------------------------------------
+// A vertical step changes a column from that column alone, so consecutive vertical steps are queued and go out as ONE
+// pass over the columns (k_vertical_fused) when something else wants the grid: any other entry point, a lateral
+// step, or a full queue.  What the host tracks per step (the plane a deposit pushes into, the bound on the column
+// lengths, the pristine state) is settled when the step is queued; a deposit that could meet a full column, outgrow
+// the Lmax the caller sees or find no plane to spare is not queued: it flushes and takes the one-step protocol.
+namespace {
+int flush_vertical(cg_grid* g) {
+    if (g->vq.empty()) return CG_OK;
+    std::vector<cg_grid::VQOp> ops; ops.swap(g->vq);
+    if (ops.size() == 1) {
+        const cg_grid::VQOp& o = ops[0];
+        ProfScope ps(g, o.etch ? CG_K_ETCH_VERTICAL : CG_K_DEPO_VERTICAL);
+        if (o.etch) launch_vertical<true>(g, o.mask, o.mat, o.t, -1, false);
+        else launch_vertical<false>(g, o.mask, o.mat, o.t, o.P, o.fresh);
+        HIPCHK(g, hipGetLastError());
+        return CG_OK;
+    }
+    FusedOps F = {};
+    F.n = (int)ops.size(); F.fresh = ops[0].fresh ? 1 : 0;
+    for (int k = 0; k < FUSE_MAX; k++) F.op[k].mask_ix = -1;
+    for (int k = 0; k < F.n; k++) {
+        const cg_grid::VQOp& o = ops[k];
+        F.op[k].t = o.t; F.op[k].vo = vert_opts(g, o.t, o.etch);
+        F.op[k].etch = o.etch ? 1 : 0; F.op[k].mat = o.mat; F.op[k].P = o.P;
+        if (o.mask) {                                      // a mask used by several steps of the run is loaded once
+            int m = 0;
+            while (m < F.nmask && F.masks[m] != o.mask) m++;
+            if (m == F.nmask) F.masks[F.nmask++] = o.mask;
+            F.op[k].mask_ix = m;
+        }
+    }
+    if (F.fresh) {
+        // The leading deposits without a mask leave every column of the reset grid the same: _depoAtTop_ (cg1:397-426)
+        // on that one column here, with the quantiser in its literal form (which the device's forms equal by construction).
+        uint32_t top = 0;
+        const auto z1 = [](uint32_t r) { return r & 0xffffu; };
+        const auto make = [](uint32_t q, int mat, int lnk) { return (q & 0xffffu) | ((uint32_t)(mat & 255) << 16) | REC_LAYER | ((uint32_t)lnk << LNK_SHIFT); };
+        int k = 0;
+        for (; k < F.n && k < FUSE_UNI_MAX && !ops[k].etch && !ops[k].mask; k++) {
+            const uint32_t q = quantz_host((double)z1(top) * g->zscale + ops[k].t, g->zscale);
+            F.uni_pushed[k] = 0;
+            if (top != 0 && (int)((top >> 16) & 255u) == ops[k].mat) top = (top & 0xffff0000u) | q;
+            else { F.uni_pushed[k] = top; top = make(q, ops[k].mat, top != 0 ? ops[k].P : LNK_NONE); }
+        }
+        F.nuni = k; F.uni_top = top;
+    }
+    const size_t nb = (g->N / 4 + 255) / 256;
+    ProfScope ps(g, CG_K_VERTICAL_FUSED);
+    const dim3 gridF((unsigned)std::max<size_t>(1, nb));
+    switch (F.nuni) {
+    case 0: hipLaunchKernelGGL(k_vertical_fused<0>, gridF, dim3(256), 0, g->stream, view(g), F); break;
+    case 1: hipLaunchKernelGGL(k_vertical_fused<1>, gridF, dim3(256), 0, g->stream, view(g), F); break;
+    case 2: hipLaunchKernelGGL(k_vertical_fused<2>, gridF, dim3(256), 0, g->stream, view(g), F); break;
+    default: hipLaunchKernelGGL(k_vertical_fused<3>, gridF, dim3(256), 0, g->stream, view(g), F); break;
+    }
+    HIPCHK(g, hipGetLastError());
+    return CG_OK;
+}
+
+int enqueue_vertical(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t) {
+    cg_grid::VQOp op{mask, etch, mat, t, -1, false};
+    if (!etch) {
+        if (g->len_bound >= g->lmax || g->len_bound + 1 > g->lmax_vis || g->nextp >= std::min(g->lmax, SPLIT_PLANES)) {
+            int rc = flush_vertical(g); if (rc) return rc;
+            return run_depo_vertical(g, mask, mat, t);
+        }
+        op.P = g->nextp++;
+        op.fresh = g->pristine;
+        g->pristine = false;
+        if (g->len_bound < 255) g->len_bound += 1;
+    }
+    g->len_valid = false;
+    g->vq.push_back(op);
+    if ((int)g->vq.size() >= FUSE_MAX) return flush_vertical(g);
+    return CG_OK;
+}
+}  // namespace
+
 // =============================================================================================
 extern "C" {
 
@@ -1027,6 +1114,7 @@ int cg_create_slab(int nx_global, int ny, int i0, int nx_local, double dx, doubl
         return fail(nullptr, CG_ERR_ARG, "bad domain: nx_global=%d ny=%d i0=%d nx_local=%d dx=%g dy=%g zscale=%g", nx_global, ny, i0,
                     nx_local, dx, dy, zscale);
     cg_grid* g = new cg_grid();
+    g->fuse = getenv("CG_NO_FUSE") == nullptr;
     hipError_t e = hipGetDevice(&g->device);
     if (e != hipSuccess) { int rc = fail(nullptr, CG_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e)); delete g; return rc; }
     g->nx = nx_local; g->ny = ny; g->nx_global = nx_global; g->i0 = i0;
@@ -1079,6 +1167,7 @@ int cg_create(double lx, double ly, double dx, double dy, int lmax_init, double 
 int cg_destroy(cg_grid* g) {
     if (!g) return CG_OK;
     (void)hipSetDevice(g->device);
+    g->vq.clear();
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     free_planes(g);
     for (auto m : g->masks) if (m) (void)hipFree(m);
@@ -1346,7 +1435,7 @@ int cg_mask_destroy(cg_grid* g, int mask_id) {
 // ---- steps ----------------------------------------------------------------------------------
 int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thickness, double conformality, int has_lower, int has_upper,
                      int* radius_rows) {
-    NEED_H(g);
+    NEED_H0(g);
     if (radius_rows) *radius_rows = 0;
     if (kind != CG_STENCIL_DEPOSIT && kind != CG_STENCIL_ETCH) return fail(g, CG_ERR_ARG, "bad stencil kind %d", kind);
     if (g->pend.active) return fail(g, CG_ERR_STATE, "a stencil step is already open");
@@ -1358,6 +1447,10 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     if (!(t > 0)) return CG_OK;                                           // cg1:437, 600
     const double S = std::isnan(conformality) ? 0.0 : std::max(0.0, std::min(1.0, conformality));   // cg1:440, 603
     const double latRange = t * S;
+    // a vertical step joins the queue of vertical steps when the fused kernel can take it; anything else first
+    // launches what is queued
+    const bool can_fuse = latRange < std::min(g->dx, g->dy) && g->fuse && !g->stats_on && g->N % 4 == 0;
+    if (!can_fuse) { int rcf = flush_vertical(g); if (rcf) return rcf; }
     // a reset grid whose first step is a deposit everywhere needs no clearing pass: the kernel writes
     // top of every column itself
     const bool fresh = g->pristine && kind == CG_STENCIL_DEPOSIT && latRange < std::min(g->dx, g->dy) && !mask && g->N % 4 == 0 && g->lmax >= 1;
@@ -1366,11 +1459,13 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     stats_begin(g);
     if (kind == CG_STENCIL_DEPOSIT && mat == CG_MAT_CAVITY) g->has_cavity = true;      // a "cavity" laid down as a film
     if (latRange < std::min(g->dx, g->dy)) {                              // cg1:445, 609
+        if (can_fuse && g->split) return enqueue_vertical(g, kind == CG_STENCIL_ETCH, mask, mat, t);
+        { int rcf = flush_vertical(g); if (rcf) return rcf; }
         if (kind == CG_STENCIL_DEPOSIT) return run_depo_vertical(g, mask, mat, t);
         const dim3 grid(blocks_for(g->N)), blk(256);
         if (g->split && g->N % 4 == 0) {    // 4 columns per thread, no look at the lengths
             ProfScope ps(g, CG_K_ETCH_VERTICAL);
-            launch_vertical<true>(g, mask, mat, t, -1);
+            launch_vertical<true>(g, mask, mat, t, -1, false);
             g->len_valid = false;
         } else {
             int rcl = ensure_len(g); if (rcl) return rcl;

@@ -377,7 +377,7 @@ int cg_step_stats(cg_grid* g, int enable, uint64_t stats[CG_NSTAT]);
  * per kernel kind since the previous call, clears them, and sets the enabled state. */
 #define CG_K_DEPO_VERTICAL   0   /* k_vertical_g4<deposit> (k_vertical_1 when N % 4 != 0)       */
 #define CG_K_ETCH_VERTICAL   1   /* k_vertical_g4<etch>                                          */
-#define CG_K_SNAPSHOT        2   /* not used any more (lateral steps read the tops directly)   */
+#define CG_K_VERTICAL_FUSED  2   /* k_vertical_fused: a run of consecutive vertical steps in one pass over the columns */
 #define CG_K_HALO            3   /* k_halo_pack, k_ghost_pack                                  */
 #define CG_K_STENCIL_DEPOSIT 4   /* k_stencil_stream / k_stencil_sym <deposit> (k_stencil_apply for radius > 8) */
 #define CG_K_STENCIL_ETCH    5   /* k_stencil_stream / k_stencil_sym <etch>                        */
