@@ -616,12 +616,13 @@ __global__ __launch_bounds__(256) void k_vertical_g4(GridView g, const uint8_t* 
 // they also stay in registers, so an etch later in the run that needs "the interval below" of a layer laid down by
 // the run finds it there (a link that names one of the run's planes) and only goes to memory for older intervals.
 constexpr int FUSE_MAX = 6;
-struct FusedOp { double t; VertOpts vo; int etch, mat, P, mask_ix; };             // mask_ix: index into FusedOps::masks, -1 = no mask
+struct FusedOp { double t; VertOpts vo; int etch, mat, P, pad_; };
 // fresh: the run starts on a reset grid (every column empty, nothing to load).  Its first `nuni` steps are then deposits
 // without a mask, which leave every column the same: the host has worked that column out (uni_top, and what each of
 // those steps pushed, uni_pushed, 0 = nothing), and the kernel starts from it with step nuni.
 constexpr int FUSE_UNI_MAX = 3;
-struct FusedOps { FusedOp op[FUSE_MAX]; const uint8_t* masks[FUSE_MAX]; int n, fresh, nmask, nuni; uint32_t uni_top, uni_pushed[FUSE_MAX]; uint32_t pad_; };
+// masks[k]: the mask of step k, null = none.  rt_shift: log2 of the tiles per image row when that is a power of two above 1, else -1.
+struct FusedOps { FusedOp op[FUSE_MAX]; const uint8_t* masks[FUSE_MAX]; int n, fresh, rt_shift, nuni; uint32_t uni_top, uni_pushed[FUSE_MAX]; uint32_t pad_; };
 
 // The intervals below the tops r[] of the columns in `want`: from the registers of the run's deposits before step k
 // where the link names one of their planes, else from memory.
@@ -647,29 +648,24 @@ template <int NUNI>
 __global__ __launch_bounds__(256) void k_vertical_fused(GridView g, const FusedOps F) {
     const size_t ngroups = g.N >> 2;
     const size_t ntiles = (ngroups + 255) / 256;
-    size_t tile = blockIdx.x;
+    unsigned tile = blockIdx.x;
     if (tile >= ntiles) return;
     // (tiles of image row r rotated by r, as in k_vertical_g4)
-    const size_t row_tiles = ((size_t)(g.ny >> 2) % 256 == 0) ? (size_t)(g.ny >> 2) / 256 : 0;
-    if (row_tiles > 1) { const size_t r = tile / row_tiles, q = tile - r * row_tiles; tile = r * row_tiles + (q + r) % row_tiles; }
-    const size_t gi = tile * 256 + threadIdx.x;
+    if (F.rt_shift > 0) { const unsigned rt = 1u << F.rt_shift, r = tile >> F.rt_shift, q = tile & (rt - 1u); tile = (r << F.rt_shift) + ((q + r) & (rt - 1u)); }
+    const size_t gi = (size_t)tile * 256 + threadIdx.x;
     if (gi >= ngroups) return;
     const size_t c0 = gi << 2;
     // every load of the lane goes out before anything is looked at: the run's distinct masks (4 bytes each) and the tops
-    unsigned mw[FUSE_MAX];
-#pragma unroll
-    for (int m = 0; m < FUSE_MAX; m++) { mw[m] = 0u; if (m < F.nmask) mw[m] = *(const unsigned*)(F.masks[m] + c0); }
-    u32x4 tv = (u32x4)(0);
-    if (!F.fresh) tv = ld_rec4(g.top + c0);
     unsigned open[FUSE_MAX], any_open = 0;               // the mask bytes of the 4 columns for step k (non-zero byte = open)
 #pragma unroll
     for (int k = 0; k < FUSE_MAX; k++) {
-        unsigned w = 0x01010101u;
-#pragma unroll
-        for (int m = 0; m < FUSE_MAX; m++) w = (F.op[k].mask_ix == m) ? mw[m] : w;
-        open[k] = k < F.n ? w : 0u;
-        any_open |= open[k];
+        open[k] = k < F.n ? 0x01010101u : 0u;
+        if (k < F.n && F.masks[k]) open[k] = *(const unsigned*)(F.masks[k] + c0);      // (a mask used twice comes from the cache the second time)
     }
+    u32x4 tv = (u32x4)(0);
+    if (!F.fresh) tv = ld_rec4(g.top + c0);
+#pragma unroll
+    for (int k = 0; k < FUSE_MAX; k++) any_open |= open[k];
     if (!any_open) return;
     if (NUNI > 0) { tv[0] = F.uni_top; tv[1] = F.uni_top; tv[2] = F.uni_top; tv[3] = F.uni_top; }
     uint32_t r[4] = {tv[0], tv[1], tv[2], tv[3]};
@@ -695,7 +691,7 @@ __global__ __launch_bounds__(256) void k_vertical_fused(GridView g, const FusedO
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 qn[j] = rec_z1(r[j]) + (uint32_t)op.vo.depo_k;
-                if (CG_ON(opn, j) && (op.vo.depo_k < 0 || qn[j] > 65535u)) slow |= 1u << j;
+                if (CG_ON(opn, j) & ((op.vo.depo_k < 0) | (qn[j] > 65535u))) slow |= 1u << j;
             }
             if (slow) {
 #pragma unroll
@@ -704,9 +700,10 @@ __global__ __launch_bounds__(256) void k_vertical_fused(GridView g, const FusedO
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t rc = r[j];
-                const bool on = CG_ON(opn, j), some = rc != 0, same = some && rec_mat(rc) == matId;
+                // (& and | on purpose: both sides are cheap, and a short circuit would cost a branch per column)
+                const bool on = CG_ON(opn, j), some = rc != 0, same = some & (rec_mat(rc) == matId);
                 const uint32_t ext = rec_with_z1(rc, qn[j]), app = rec_make_l(qn[j], matId, some ? op.P : LNK_NONE);
-                pushed[k][j] = (on && some && !same) ? rc : 0u;
+                pushed[k][j] = (on & some & !same) ? rc : 0u;
                 r[j] = on ? (same ? ext : app) : rc;
             }
             continue;
@@ -715,7 +712,7 @@ __global__ __launch_bounds__(256) void k_vertical_fused(GridView g, const FusedO
         const bool isAll = (matId == 255);
         unsigned act = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) act |= (CG_ON(opn, j) && etchable(r[j], matId, isAll)) ? (1u << j) : 0u;
+        for (int j = 0; j < 4; j++) act |= (CG_ON(opn, j) & (r[j] != 0) & (isAll | (rec_mat(r[j]) == matId))) ? (1u << j) : 0u;
         if (!act) continue;
         // the intervals below the tops: from the registers of the run's deposits where the link names one of their planes
         uint32_t b[4]; unsigned mem = 0;
@@ -726,11 +723,11 @@ __global__ __launch_bounds__(256) void k_vertical_fused(GridView g, const FusedO
 #pragma unroll
             for (int q = 0; q < FUSE_MAX; q++) {
                 if (q >= k) continue;
-                const bool m = !F.op[q].etch && F.op[q].P == p;
-                bj = m ? pushed[q][j] : bj; inreg = inreg || m;
+                const bool m = (F.op[q].etch == 0) & (F.op[q].P == p);
+                bj = m ? pushed[q][j] : bj; inreg = inreg | m;
             }
             b[j] = bj;
-            if (((act >> j) & 1) && p != LNK_NONE && !inreg) mem |= 1u << j;
+            if ((((act >> j) & 1) != 0) & (p != LNK_NONE) & !inreg) mem |= 1u << j;
         }
         if (mem) load_below4(g, c0, mem, r, b);
         double rem[4] = {op.t, op.t, op.t, op.t};
@@ -740,11 +737,11 @@ __global__ __launch_bounds__(256) void k_vertical_fused(GridView g, const FusedO
             for (int j = 0; j < 4; j++) {
                 const uint32_t rc = r[j], below = rec_lnk(rc) != LNK_NONE ? b[j] : 0u;
                 const int d = (int)rec_z1(rc) - (int)rec_z1(below);
-                const bool a = (act >> j) & 1, cut = d >= op.vo.etch_kc, on = d <= op.vo.etch_kr;       // cg1:574-578 / goes on below
+                const bool a = ((act >> j) & 1) != 0, cut = d >= op.vo.etch_kc, on = d <= op.vo.etch_kr;       // cg1:574-578 / goes on below
                 const uint32_t rnew = cut ? rec_with_z1(rc, rec_z1(rc) - (uint32_t)op.vo.etch_ke) : below;   // cg1:579-587: the layer goes, and done
-                r[j] = (a && (cut || !on)) ? rnew : rc;
-                general |= (a && !cut && on) ? (1u << j) : 0u;
-                holes |= (a && !cut && !on && rec_hole(below)) ? (1u << j) : 0u;
+                r[j] = (a & (cut | !on)) ? rnew : rc;
+                general |= (a & !cut & on) ? (1u << j) : 0u;
+                holes |= (a & !cut & !on & rec_hole(below)) ? (1u << j) : 0u;
             }
             if (holes) {                                       // a gap under the removed layer goes with it
 #pragma unroll

@@ -1040,17 +1040,16 @@ int flush_vertical(cg_grid* g) {
     }
     FusedOps F = {};
     F.n = (int)ops.size(); F.fresh = ops[0].fresh ? 1 : 0;
-    for (int k = 0; k < FUSE_MAX; k++) F.op[k].mask_ix = -1;
     for (int k = 0; k < F.n; k++) {
         const cg_grid::VQOp& o = ops[k];
         F.op[k].t = o.t; F.op[k].vo = vert_opts(g, o.t, o.etch);
         F.op[k].etch = o.etch ? 1 : 0; F.op[k].mat = o.mat; F.op[k].P = o.P;
-        if (o.mask) {                                      // a mask used by several steps of the run is loaded once
-            int m = 0;
-            while (m < F.nmask && F.masks[m] != o.mask) m++;
-            if (m == F.nmask) F.masks[F.nmask++] = o.mask;
-            F.op[k].mask_ix = m;
-        }
+        F.masks[k] = o.mask;
+    }
+    F.rt_shift = -1;
+    if ((g->ny >> 2) % 256 == 0) {
+        const unsigned rt = (unsigned)((g->ny >> 2) / 256);
+        if (rt > 1 && (rt & (rt - 1)) == 0) F.rt_shift = __builtin_ctz(rt);
     }
     if (F.fresh) {
         // The leading deposits without a mask leave every column of the reset grid the same: _depoAtTop_ (cg1:397-426)
