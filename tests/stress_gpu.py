@@ -25,4 +25,8 @@ for seed in range(50, 62):
     nx, ny = 80 + 4 * ((seed * 29) % 50), 72 + 4 * ((seed * 41) % 50)
     t.test_random_flow_with_strip_cmp_cavity_vs_oracle(nx, ny, seed)
     print("strip/cmp seed", seed, nx, ny, "ok", flush=True)
+for seed in range(70, 110):
+    nx, ny = 32 + 4 * ((seed * 29) % 40), 36 + 4 * ((seed * 41) % 60)
+    t.test_runs_of_vertical_steps_in_one_launch(nx, ny, seed)
+    print("fused runs seed", seed, nx, ny, "ok", flush=True)
 print("stress ok")

@@ -738,6 +738,65 @@ def test_other_pitches_and_height_steps(dx, zs, lmax):
     g.close()
 
 
+@pytest.mark.parametrize("nx,ny,seed", [(96, 128, 21), (61, 64, 22), (128, 260, 23), (40, 52, 24)])
+def test_runs_of_vertical_steps_in_one_launch(nx, ny, seed):
+    """Consecutive vertical steps are queued and applied in one pass over the columns (k_vertical_fused) when something
+    else looks at the grid.  Seeded runs of 1..9 vertical steps (the queue holds 6) with and without masks, thicknesses
+    with and without an integer licence, extensions by the same material, etches that take several of the run's own
+    layers and go on into older ones, blanket deposits on a reset grid (worked out on the host), a reset, a snapshot
+    and the release of a mask while steps are queued -- the state is compared with the oracle only between runs, so the
+    steps of a run really go out together.  One grid also holds gaps (STRIP) that the etches uncover."""
+    fem = _engine()
+    rng = _lcg(seed)
+    L = 2 * max(nx, ny)
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    reds = [fem.reduce_mask(_random_mask_data(rng, L, 9)) for _ in range(3)]
+    masks = [(g.mask_from_shapes(r), o.mask_raster(r)) for r in reds]
+    ts = [0.04, 0.05, 1.0, 2.5, 4, 6, 7.25, 10, 13.05, 21, 26.05, 55]
+    checked = 0
+    g.profile(True)
+    for run in range(14):
+        n = 1 + next(rng) % 9
+        if run in (0, 5, 9):                               # a reset with nothing (or a queue) pending, then blanket films
+            g.createNewGrid(); o.reset()
+            steps = [("d", None, 3 + k % 3, [30, 20, 2.5, 10, 7.25][k % 5]) for k in range(1 + next(rng) % 5)]
+            if run == 9:
+                steps[1:1] = [("d", None, steps[0][2], 4)]                             # the same material twice: an extension
+        else:
+            steps = []
+        for _ in range(n):
+            kind = "d" if next(rng) % 5 < 2 else "e"
+            mi = next(rng) % 4
+            mat = [3, 4, 5, 6, 255][next(rng) % (5 if kind == "e" else 4)]
+            steps.append((kind, mi if mi < 3 else None, mat, ts[next(rng) % len(ts)]))
+        for kind, mi, mat, t in steps:
+            gm, om = (None, None) if mi is None else masks[mi]
+            (g.deposit_general if kind == "d" else g.etch_general)(gm, mat, t, 0)
+            (o.deposit_general if kind == "d" else o.etch_general)(om, mat, t, 0)
+        if run == 3:                                       # a snapshot taken and the grid wrecked and restored, steps queued on both sides
+            g.snapshot_save(5)
+            g.etch_general(None, 255, 500, 0); g.deposit_general(None, 7, 3, 0)
+            g.snapshot_load(5); g.snapshot_drop(5)
+            g.deposit_general(masks[0][0], 7, 1.5, 0); o.deposit_general(masks[0][1], 7, 1.5, 0)
+        if run == 6:                                       # a mask released and made again while steps that use it are queued
+            g.etch_general(masks[2][0], 255, 3.3, 0); o.etch_general(masks[2][1], 255, 3.3, 0)
+            masks[2][0].destroy()
+            masks[2] = (g.mask_from_shapes(reds[2]), masks[2][1])
+        if run == 7 and seed % 2 == 1:                     # gaps under the tops: a lateral deposit over strips leaves holes to uncover
+            g.strip_connected(4); o.strip_connected(4)
+            g.deposit_general(None, 6, 5, 1.0); o.deposit_general(None, 6, 5, 1.0)
+            if o.arrays()[0].max() >= o.Lmax:
+                break
+        assert g.checksum() == o.checksum(), f"run {run}: {steps}"
+        assert g.Lmax == o.Lmax and g.maxHeight() == o.max_height(), f"run {run}"
+        checked += 1
+    assert checked >= 8
+    assert g.profile(False).get("k_vertical_fused", (0, 0))[1] >= 8              # (the runs did go out as fused launches)
+    _assert_same(g, o.arrays(), "final")
+    g.close()
+
+
 @pytest.mark.parametrize("t_etch,S", [(12.0, 1.0), (10.0, 1.0), (16.4, 0.5)])
 def test_isotropic_overetch_rows_without_neighbours(t_etch, S):
     """An isotropic etch deeper than the film it takes off: the streaming lateral kernel updates the rows at the head of

@@ -47,6 +47,8 @@ import re
 
 def parse(k):
     """-> (bench.py's group label, keeps statistics) of a step kernel, or None."""
+    if k.startswith("k_vertical_fused"):  # a run of vertical steps in one launch: never keeps statistics
+        return "k_vertical_fused", False
     m = re.match(r"k_(stencil_stream|stencil_sym|stencil_apply|vertical_g4|vertical_1)<(.*)>", k)
     if not m:
         return None
