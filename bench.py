@@ -282,6 +282,8 @@ def main():
         # the roofline object is about ONE step's kernel: a fused launch's algorithmic bytes are the sum of its steps', which
         # says how much traffic the fusion saved, not how close the launch runs to the memory rate
         cand = {n_: v for n_, v in kernels.items() if "GBps" in v and n_ != "k_vertical_fused"}
+        if not cand:                              # a flow of vertical steps only (C2): nothing but fused launches to report
+            cand = {n_: v for n_, v in kernels.items() if "GBps" in v}
         dom = max(cand, key=lambda n_: cand[n_]["ms_total"]) if cand else None
         roofline = None
         # HBM traffic per launch from the PMC passes of the same command (tools/prof.sh), when committed
@@ -298,7 +300,7 @@ def main():
             achieved = cand[dom]["GBps"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                         "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "launches": cand[dom]["launches"], "ms_avg": cand[dom]["ms_avg"],
+                        "launches": cand[dom]["launches"], "ms_avg": cand[dom]["ms_avg"], "fused_steps_per_launch": (fused_steps / max(1, fused_launches)) if dom == "k_vertical_fused" else 1,
                         "algorithmic_bytes_per_launch": int(kbytes[dom] / max(1, cand[dom]["launches"]))}
         total_alg = sum(step_bytes[(k + q) % len(flow)] for q in range(args.steps))
         cols = nxl * ny * world * args.steps

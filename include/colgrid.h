@@ -17,6 +17,9 @@
  * (0 = ok) and never throws.  A handle is not re-entrant: use it from one thread at a time.
  * All work of a handle is enqueued on one HIP stream (its own, or the one given to
  * cg_set_stream); entry points that return data to the host synchronise that stream.
+ * Vertical steps (cg_deposit_general / cg_etch_general / cg_stencil_begin with t*S < min(dx, dy))
+ * are queued in the handle, up to six, and launched together by the next entry point that is not
+ * such a step (cg_sync included): same results, one pass over the columns instead of one per step.
  *
  * The comment above each declaration names the reference interface it stands in for.
  * "cg1/cg2/rt/sl" = template/script_columngrid.js, script_columngrid2.js,

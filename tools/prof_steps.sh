@@ -1,12 +1,14 @@
 #!/bin/bash
 # per-dispatch HBM traffic of every grid kernel of one flow pass (rocprofv3 PMC, two runs)
 TAG=${1:-steps}
+SCRIPT=${2:-tools/step_times.py}     # tools/fused_times.py: the same per launch with runs of vertical steps fused
+export REPS=2
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 tools/step_times.py > $OUT/fetch.log 2>&1 || { tail -5 $OUT/fetch.log; exit 1; }
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/step_times.py > $OUT/write.log 2>&1 || { tail -5 $OUT/write.log; exit 1; }
-timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 tools/step_times.py > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $SCRIPT > $OUT/fetch.log 2>&1 || { tail -5 $OUT/fetch.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $SCRIPT > $OUT/write.log 2>&1 || { tail -5 $OUT/write.log; exit 1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $SCRIPT > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 python3 - <<PY
 import csv, glob
 def rows(pat):
