@@ -9,8 +9,9 @@ to every column (vertical deposit, masked anisotropic etch, conformal deposit or
 etch); when the flow wraps, the grid is re-created (createNewGrid) inside the timed region, as
 the reference's runtime does at the start of a rebuild (template/script_runtime.js:219-222).
 With N > 1 every rank owns one 16384-row slab of a (16384*N) x 16384 domain (weak scaling, the
-default) or, with --scaling strong, 16384/N rows of ONE 16384 x 16384 domain; the stencil steps
-exchange R boundary rows with the neighbouring ranks over RCCL.
+default; every slab carries the N = 1 mask pattern, so the work per GPU stays what it is at N = 1) or,
+with --scaling strong, 16384/N rows of ONE 16384 x 16384 domain; the stencil steps exchange R boundary
+rows with the neighbouring ranks over RCCL.  Consecutive vertical steps go out as one fused launch.
 
 The bench checks what it timed: the checksum of the grid after the timed region must equal the
 checksum an untimed pass (other kernel instantiations: the ones that keep statistics) reached at
@@ -45,16 +46,20 @@ def parse():
     return ap.parse_args()
 
 
-def build_masks(fem, flows, grid, specs, names, nx, ny, i0, LX, LY, device):
+def build_masks(fem, flows, grid, specs, names, nx, ny, i0, LX, LY, device, shift_x_nm=0.0):
     """Device rasters for the masks a flow uses, made by the engine's rasteriser from the fabric-style
     shape records of the reference (periodic masks: the shapes that reach this rank's rows), and checked
-    against the closed form of the periodic ones."""
+    against the closed form of the periodic ones.  shift_x_nm moves the shapes of the non-periodic masks
+    along x (weak scaling: every slab gets its own copy of the pattern, see main)."""
     import torch
     out = {}
     for name in names:
         spec = specs[name]
         if spec["kind"] == "shapes":
-            out[name] = grid.mask_from_shapes(fem.reduce_mask(spec["data"], packed=True))
+            data = spec["data"]
+            if shift_x_nm:
+                data = {"objects": [dict(o, left=o["left"] + shift_x_nm) for o in data["objects"]]}
+            out[name] = grid.mask_from_shapes(fem.reduce_mask(data, packed=True))
             continue
         data = flows.shapes_of(spec, LX, LY, x_range=(2.0 * i0, 2.0 * (i0 + nx)))
         out[name] = grid.mask_from_shapes(fem.reduce_mask(data, packed=True))
@@ -167,13 +172,19 @@ def main():
         nxl, nxg = args.n, args.n * world
     LX, LY = 2.0 * nxg, 2.0 * ny
     flow = flows.FLOWS[args.flow]()
-    specs = flows.mask_specs(LX)
+    # Weak scaling keeps the work of every GPU what it is at N = 1: the masks that are not periodic (a window, three
+    # shapes) are laid out once per slab -- the N = 1 pattern repeated along x -- instead of being stretched over the
+    # whole domain, which would leave some slabs fully open and others fully blocked.  Strong scaling cuts the one
+    # N = 1 domain, pattern and all.
+    weak_many = world > 1 and nxg != args.n
+    specs = flows.mask_specs(2.0 * nxl if weak_many else LX)
+    shift_x = 2.0 * rank * nxl if weak_many else 0.0
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         grid = fem_amd.ColumnGrid(dx=2.0, dy=2.0, slab=(nxg, ny, rank * nxl, nxl))
         grid.set_stream(stream.cuda_stream)
         names = sorted({s["mask"] for s in flow if s["mask"]})
-        masks = build_masks(fem_amd, flows, grid, specs, names, nxl, ny, rank * nxl, LX, LY, device)
+        masks = build_masks(fem_amd, flows, grid, specs, names, nxl, ny, rank * nxl, LX, LY, device, shift_x)
         slab = SlabGrid(grid, rank, world, device=device, dx=2.0, dy=2.0, ny=ny, stream=stream)
 
         # C5 also extracts cross-sections after every step: 64 YZ lines at i = 512 s + 256 and 64 XZ lines
@@ -311,6 +322,7 @@ def main():
             "data": "synthetic", "flow": args.flow, "n": args.n,
             "config": {"workload": f"{args.flow.upper()} flow ({len(flow)} process steps, 3 masks{', 128 cross-sections after every step' if slice_idx else ''}) on a {nxl}x{ny} column grid per GPU",
                        "grid": [nxg, ny], "rows_per_gpu": nxl, "lmax": grid.Lmax, "parallelism": f"slab{world}",
+                       "masks": "the N=1 masks, the non-periodic ones repeated once per slab" if weak_many else "as N=1",
                        "world": dist.get_world_size() if world > 1 else 1},
             "halo": {"bytes_sent_per_rank": halo_b, "bytes_per_step": round(halo_b / max(1, args.steps), 1),
                      "exchange_ms_total": round(swap_s * 1e3, 3)},

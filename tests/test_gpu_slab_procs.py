@@ -40,3 +40,23 @@ def test_bench_strong_scaling_rehearsal():
     assert b["config"]["grid"] == a["config"]["grid"] == [256, 256] and b["config"]["rows_per_gpu"] == 128
     assert b["checksum"] == a["checksum"]
     assert b["halo"]["bytes_sent_per_rank"] > 0 and a["halo"]["bytes_sent_per_rank"] == 0
+
+
+@pytest.mark.gpu
+def test_bench_weak_scaling_rehearsal():
+    """bench.py with 2 ranks on one GPU in its default (weak) mode: every rank owns a slab of the N = 1 size that
+    carries its own copy of the non-periodic masks, so the checksum of the two-slab domain is the sum of two
+    one-slab grids whose patterns differ only by the phase of the 48 nm discs; the bench's own check of the timed
+    state (fused launches against the statistics pass and an unfused-order replay) runs on both ranks."""
+    import json
+    root = os.path.dirname(HERE)
+    common = ["--size", "256", "--flow", "c4", "--steps", "20", "--warmup", "20", "--no-cpu"]
+    env = dict(os.environ, BENCH_ONE_GPU="1", BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29657", os.path.join(root, "bench.py"), "--gpus", "2"] + common
+    two = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+    b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["scaling"] == "weak" and b["n_gpus"] == 2 and b["config"]["world"] == 2
+    assert b["config"]["grid"] == [512, 256] and b["config"]["rows_per_gpu"] == 256
+    assert b["halo"]["bytes_sent_per_rank"] > 0 and b["fusion"]["fused_launches"] == 3
