@@ -2302,10 +2302,17 @@ __device__ __forceinline__ int store_reference_row(At at, int l, int L, uint8_t*
 // split form's chain runs top-down, so its intervals (at most LNK_NONE + 1) are first collected in a small per-lane array.
 __device__ __forceinline__ int gather_column(const GridView& g, size_t c, int count_chain, int L, uint8_t* __restrict__ mrow, uint16_t* __restrict__ zrow) {
     if (g.split) {
+        // one walk down the chain: the intervals are collected top first and handed out bottom first (the chain says how
+        // long it is, so neither len[] nor a walk of its own to count is needed)
         uint32_t col[LNK_NONE + 1];
-        const int l = min(count_chain ? chain_length(g, c) : (int)g.len[c], LNK_NONE + 1);
-        load_column(g, c, l, col);
-        return store_reference_row([&](int k) { return col[k]; }, l, L, mrow, zrow);
+        int n = 0;
+        uint32_t x = g.top[c];
+        while (x != 0 && n <= LNK_NONE) {
+            col[n++] = x & REC_BODY;
+            const int p = rec_lnk(x);
+            x = p == LNK_NONE ? 0u : g.rec[(size_t)p * g.N + c];
+        }
+        return store_reference_row([&](int k) { return col[n - 1 - k]; }, n, L, mrow, zrow);
     }
     const uint32_t* __restrict__ rc = g.rec + c;
     const size_t N = g.N;
