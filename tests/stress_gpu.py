@@ -1,5 +1,5 @@
 """Wider seeded sweeps of the GPU-vs-oracle parity tests (not collected by pytest; run on a GPU box as
-`python tests/stress_gpu.py`): the random-flow tests of test_gpu_parity.py with 48 more seeds and sizes."""
+`python tests/stress_gpu.py`): the random-flow tests of test_gpu_parity.py with 88 more seeds and sizes."""
 import os
 import sys
 
