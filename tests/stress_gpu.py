@@ -27,6 +27,6 @@ for seed in range(50, 62):
     print("strip/cmp seed", seed, nx, ny, "ok", flush=True)
 for seed in range(70, 110):
     nx, ny = 32 + 4 * ((seed * 29) % 40), 36 + 4 * ((seed * 41) % 60)
-    t.test_runs_of_vertical_steps_in_one_launch(nx, ny, seed)
+    t._check_runs_of_vertical_steps(nx, ny, seed, [0.1, 0.05, 0.2, 0.1][seed % 4])
     print("fused runs seed", seed, nx, ny, "ok", flush=True)
 print("stress ok")

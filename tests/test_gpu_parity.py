@@ -738,8 +738,12 @@ def test_other_pitches_and_height_steps(dx, zs, lmax):
     g.close()
 
 
-@pytest.mark.parametrize("nx,ny,seed", [(96, 128, 21), (61, 64, 22), (128, 260, 23), (40, 52, 24)])
-def test_runs_of_vertical_steps_in_one_launch(nx, ny, seed):
+@pytest.mark.parametrize("nx,ny,seed,zs", [(96, 128, 21, 0.1), (61, 64, 22, 0.1), (128, 260, 23, 0.05), (40, 52, 24, 0.25), (72, 96, 25, 0.07)])
+def test_runs_of_vertical_steps_in_one_launch(nx, ny, seed, zs):
+    _check_runs_of_vertical_steps(nx, ny, seed, zs)
+
+
+def _check_runs_of_vertical_steps(nx, ny, seed, zs=0.1):
     """Consecutive vertical steps are queued and applied in one pass over the columns (k_vertical_fused) when something
     else looks at the grid.  Seeded runs of 1..9 vertical steps (the queue holds 6) with and without masks, thicknesses
     with and without an integer licence, extensions by the same material, etches that take several of the run's own
@@ -749,8 +753,8 @@ def test_runs_of_vertical_steps_in_one_launch(nx, ny, seed):
     fem = _engine()
     rng = _lcg(seed)
     L = 2 * max(nx, ny)
-    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
-    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2, 32, zs)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2, 32, zs)
     reds = [fem.reduce_mask(_random_mask_data(rng, L, 9)) for _ in range(3)]
     masks = [(g.mask_from_shapes(r), o.mask_raster(r)) for r in reds]
     ts = [0.04, 0.05, 1.0, 2.5, 4, 6, 7.25, 10, 13.05, 21, 26.05, 55]
