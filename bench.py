@@ -43,7 +43,26 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-replicas", type=int, default=16, help="processes of the all-cores CPU baseline (0 = skip it)")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="how many times the timed region of --steps steps is run; ms_per_step is the median region")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD (torch.distributed.run, one rank per
+    GPU), pass its output through and leave with its exit code.  This parent never imports torch.cuda nor touches
+    the GPU, and it does not replace itself with the launcher (no exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def build_masks(fem, flows, grid, specs, names, nx, ny, i0, LX, LY, device, shift_x_nm=0.0):
@@ -140,6 +159,8 @@ def main():
         from fem_amd import flows as _flows
         print(json.dumps(cpu_baseline(_flows, _flows.FLOWS[args.flow](), args.cpu_n)), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
     import fem_amd
@@ -149,6 +170,8 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus would be wrong")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     if os.environ.get("BENCH_ONE_GPU"):      # rehearsal of the N > 1 path on a one-GPU box (use with BENCH_BACKEND=gloo)
@@ -162,6 +185,8 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
 
     ny = args.n
     if args.scaling == "strong" and world > 1:
@@ -216,23 +241,30 @@ def main():
         k = run(args.warmup, 0)
         grid.sync()
 
-        # ---- timed region
+        # ---- timed regions: --repeats times EXACTLY --steps steps, each bracketed by a barrier and a device
+        #      synchronisation on both sides; the flow simply goes on from one region into the next.  What is
+        #      reported is the MEDIAN region (minimum and maximum beside it).
+        reps = max(1, args.repeats)
         grid.profile(True)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(args.steps, k)
-        grid.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+        region_s = []
+        kk = k
+        for _ in range(reps):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            kk = run(args.steps, kk)
+            grid.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            region_s.append(time.perf_counter() - t0)
         prof = grid.profile(False)
         swap_s, halo_b, slab.swap_seconds, slab.halo_bytes = slab.swap_seconds, slab.halo_bytes, 0.0, 0
+        total_steps = args.steps * reps
 
         # ---- the state the timed region left must be the state of that step of the flow
-        last = (k + args.steps - 1) % len(flow)            # index in the flow of the last timed step
+        last = (k + total_steps - 1) % len(flow)           # index in the flow of the last timed step
         check = slab.checksum()
         slab.createNewGrid()
         for s in flow[:last + 1]:
@@ -242,10 +274,11 @@ def main():
             raise SystemExit("bench.py: the grid after the timed region does not match step %d of the flow: timed %016x, "
                              "untimed pass with statistics %016x, untimed replay %016x" % (last, check, step_check[last], replay))
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:                                 # a region takes as long as its slowest rank
+        t = torch.tensor(region_s, dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        region_s = [float(v) for v in t.tolist()]
+    dt = sorted(region_s)[len(region_s) // 2]
 
     if rank == 0:
         # algorithmic bytes of the timed steps, per kernel kind (the kernel that applies the step)
@@ -271,7 +304,7 @@ def main():
                 kd1 = kind_of(flow[run[0]])
                 kbytes[kd1] = kbytes.get(kd1, 0) + step_bytes[run[0]]
             run.clear()
-        for q in range(args.steps):
+        for q in range(total_steps):
             idx = (k + q) % len(flow)
             kd = kind_of(flow[idx])
             if idx == 0:
@@ -297,23 +330,38 @@ def main():
             cand = {n_: v for n_, v in kernels.items() if "GBps" in v}
         dom = max(cand, key=lambda n_: cand[n_]["ms_total"]) if cand else None
         roofline = None
-        # HBM traffic per launch from the PMC passes of the same command (tools/prof.sh), when committed
-        traffic, traffic_src = None, None
+        # HBM traffic per launch from the PMC passes of the same command (tools/prof.sh), when committed: the file holds
+        # fetch + write bytes per launch of every kernel group; those and the live launch times give the rate at which
+        # each group really moves bytes (traffic_GBps, traffic_frac of 8 TB/s) -- for a fused launch THIS is the
+        # memory rate, not its algorithmic figure
+        traffic, traffic_src, flow_traffic = None, None, None
         tpath = args.traffic or newest_traffic_file()
         if dom and tpath and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
             same_workload = tj.get("n") == args.n and tj.get("flow") == args.flow and tj.get("n_gpus", 1) == world
-            if same_workload and dom in tj.get("kernels", {}):
-                traffic = tj["kernels"][dom]["fetch_bytes_per_launch"] + tj["kernels"][dom]["write_bytes_per_launch"]
-                traffic_src = {"file": os.path.relpath(tpath, ROOT), "git_blob": git_blob_hash(tpath)}
+            if same_workload:
+                tk = tj.get("kernels", {})
+                for name, v in kernels.items():
+                    if name in tk and v["ms_total"] > 0:
+                        b = tk[name]["fetch_bytes_per_launch"] + tk[name]["write_bytes_per_launch"]
+                        v["traffic_bytes_per_launch"] = b
+                        v["traffic_GBps"] = round(b * v["launches"] / 1e9 / (v["ms_total"] / 1e3), 1)
+                        v["traffic_frac"] = round(v["traffic_GBps"] / 8000.0, 4)
+                timed = [n_ for n_ in kernels if n_ in kbytes]
+                if timed and all("traffic_bytes_per_launch" in kernels[n_] for n_ in timed):
+                    flow_traffic = sum(kernels[n_]["traffic_bytes_per_launch"] * kernels[n_]["launches"] for n_ in timed)
+                if dom in tk:
+                    traffic = kernels[dom]["traffic_bytes_per_launch"]
+                    traffic_src = {"file": os.path.relpath(tpath, ROOT), "git_blob": git_blob_hash(tpath)}
         if dom:
             achieved = cand[dom]["GBps"]
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                         "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "launches": cand[dom]["launches"], "ms_avg": cand[dom]["ms_avg"], "fused_steps_per_launch": (fused_steps / max(1, fused_launches)) if dom == "k_vertical_fused" else 1,
                         "algorithmic_bytes_per_launch": int(kbytes[dom] / max(1, cand[dom]["launches"]))}
-        total_alg = sum(step_bytes[(k + q) % len(flow)] for q in range(args.steps))
+        total_alg = sum(step_bytes[(k + q) % len(flow)] for q in range(total_steps))
+        total_s = sum(region_s)
         cols = nxl * ny * world * args.steps
         out = {
             "metric": "column-updates/sec per process step", "value": round(cols / dt / 1e9, 4), "unit": "Gcol/s",
@@ -324,9 +372,14 @@ def main():
                        "grid": [nxg, ny], "rows_per_gpu": nxl, "lmax": grid.Lmax, "parallelism": f"slab{world}",
                        "masks": "the N=1 masks, the non-periodic ones repeated once per slab" if weak_many else "as N=1",
                        "world": dist.get_world_size() if world > 1 else 1},
-            "halo": {"bytes_sent_per_rank": halo_b, "bytes_per_step": round(halo_b / max(1, args.steps), 1),
+            "halo": {"bytes_sent_per_rank": halo_b, "bytes_per_step": round(halo_b / max(1, total_steps), 1),
                      "exchange_ms_total": round(swap_s * 1e3, 3)},
-            "whole_flow_algorithmic_GBps": round(total_alg * world / 1e9 / dt, 1),
+            "timing": {"regions": reps, "steps_per_region": args.steps, "ms_per_step_median": round(dt * 1e3 / args.steps, 4),
+                       "ms_per_step_min": round(min(region_s) * 1e3 / args.steps, 4),
+                       "ms_per_step_max": round(max(region_s) * 1e3 / args.steps, 4),
+                       "note": "value and ms_per_step are the median region; kernel times below are sums over all regions"},
+            "whole_flow_algorithmic_GBps": round(total_alg * world / 1e9 / total_s, 1),
+            "whole_flow_traffic_GBps": round(flow_traffic * world / 1e9 / total_s, 1) if flow_traffic else None,
             "fusion": {"vertical_steps_fused": fused_steps, "fused_launches": fused_launches,
                        "note": "runs of consecutive vertical steps are applied in one pass over the columns (k_vertical_fused); "
                                "its algorithmic bytes are the sum of its steps', so its GB/s is not an HBM rate; CG_NO_FUSE=1 launches every step on its own"},
