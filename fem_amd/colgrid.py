@@ -67,6 +67,7 @@ ABI = {
     "cg_mask_from_device_raster": (_i, [_vp, _vp, _sz, C.POINTER(_i)]),
     "cg_mask_from_shapes": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(_i)]),
     "cg_mask_any_open": (_i, [_vp, _i, C.POINTER(_i)]),
+    "cg_kernel_cache_touch": (_i, [_vp, _d, _d]),
     "cg_mask_download": (_i, [_vp, _i, _vp, _sz]),
     "cg_mask_destroy": (_i, [_vp, _i]),
     "cg_deposit_general": (_i, [_vp, _i, _i, _d, _d]),
@@ -366,6 +367,11 @@ class ColumnGrid:
         a = C.c_int()
         self._chk(self.lib.cg_mask_any_open(self.h, self._mid(mask), C.byref(a)))
         return bool(a.value)
+
+    def kernel_cache_touch(self, thickness, conformality):
+        """The conformal-kernel cache gets the entry a lateral step of these parameters would create
+        (script_columngrid.js:470), without anything else happening."""
+        self._chk(self.lib.cg_kernel_cache_touch(self.h, float(thickness), float(conformality)))
 
     def mask_from_data(self, mask_data):
         red = reduce_mask(mask_data)

@@ -136,7 +136,7 @@ struct WetOut {                                                // merge of touch
 // as q0 | q1 << 16: both are at most Hq < 65536) and walked from there for every piece of every target layer; a column
 // that receives more goes back to its neighbours each time.
 constexpr int WET_CUTS = 24;
-__global__ __launch_bounds__(256) void k_wet_step(GridView s, Ghost gh, GridView d, int matId, int dtQ, int dtQDiag, int diag, unsigned Hq,
+static __global__ __launch_bounds__(256) void k_wet_step(GridView s, Ghost gh, GridView d, int matId, int dtQ, int dtQDiag, int diag, unsigned Hq,
                                                   int* __restrict__ flags) {
     __shared__ uint32_t s_cut[WET_CUTS][256];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -490,7 +490,7 @@ struct AldTap { int du, dv; double add; int lo_q, hi_q, exact, pad_; };
 
 // --- coat at thickness t (computeCoatBitsSingleT + applyCoatFromBits, cg2:699-707, 585-682) --
 // bbox = the seeds' bounding box grown by the kernel radius and clipped to the domain (cg2:510-524).
-__global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, const AldTap* __restrict__ taps, int ntaps,
+static __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hcap, const AldTap* __restrict__ taps, int ntaps,
                            const uint16_t* __restrict__ seed_n, const uint2* __restrict__ seed, int seed_planes, ArrLayout S,
                            int imin, int imax, int jmin, int jmax, int mat, int HcapQ, int* __restrict__ flags) {
     extern __shared__ uint32_t lds[];
@@ -638,7 +638,7 @@ struct CavIter {
 };
 
 // a = the state after coat + identify_cavity, b = the state before; d = b + (cavity(a) \ cavity(b))
-__global__ void k_ald_merge_cavity(GridView a, GridView b, GridView d, AldLayout L, int* __restrict__ flags) {
+static __global__ void k_ald_merge_cavity(GridView a, GridView b, GridView d, AldLayout L, int* __restrict__ flags) {
     extern __shared__ uint32_t lds[];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const BitCol bits{lds + threadIdx.x, (int)blockDim.x, L.wpc};

@@ -39,6 +39,9 @@
 // de-quantised as (double)q*zscale, re-quantised as Math.round(z/zscale) (halves toward
 // +infinity) and stored modulo 2^16 (script_columngrid.js:117-122, 85).  This file must be
 // compiled with -ffp-contract=off: the reference rounds after every operation.
+//
+// This header is included by several translation units (see cg_launch.h): kernels that are not templates have
+// internal linkage (`static __global__`), so that every unit keeps only the ones it launches.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -832,7 +835,7 @@ __device__ __forceinline__ bool tile_of_block(const GridView& g, int tiles_j, in
 
 __device__ __forceinline__ bool etchable(uint32_t r, int matId, bool isAll) { return r != 0 && (isAll || rec_mat(r) == matId); }
 
-__global__ __launch_bounds__(256) void k_halo_pack(GridView g, const uint8_t* __restrict__ mask, int matId, int etch, int Rh,
+static __global__ __launch_bounds__(256) void k_halo_pack(GridView g, const uint8_t* __restrict__ mask, int matId, int etch, int Rh,
                                                    uint8_t* __restrict__ send_lower, uint8_t* __restrict__ send_upper) {
     const bool isAll = (matId == 255);
     const size_t n = (size_t)Rh * g.ny;
@@ -1782,7 +1785,7 @@ __device__ __forceinline__ bool point_inside_shape(double x, double y, const Sha
     }
 }
 
-__global__ __launch_bounds__(256) void k_mask_shapes(int nx, int ny, int i0, double dx, double dy, const Shape* __restrict__ shapes,
+static __global__ __launch_bounds__(256) void k_mask_shapes(int nx, int ny, int i0, double dx, double dy, const Shape* __restrict__ shapes,
                                                      int nshapes, const double* __restrict__ pts, uint8_t* __restrict__ raster) {
     const size_t N = (size_t)nx * ny;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1803,7 +1806,7 @@ __global__ __launch_bounds__(256) void k_mask_shapes(int nx, int ny, int i0, dou
 // from the last shape to the first as the reference does (rt:58).
 constexpr int MASK_TILE = 32;
 
-__global__ __launch_bounds__(256) void k_mask_shapes_binned(int nx, int ny, int i0, double dx, double dy, const Shape* __restrict__ shapes,
+static __global__ __launch_bounds__(256) void k_mask_shapes_binned(int nx, int ny, int i0, double dx, double dy, const Shape* __restrict__ shapes,
                                                             const double* __restrict__ pts, int tiles_j, const int* __restrict__ tile_off,
                                                             const int* __restrict__ tile_list, const int* __restrict__ wide, int nwide,
                                                             uint8_t* __restrict__ raster) {
@@ -1824,7 +1827,7 @@ __global__ __launch_bounds__(256) void k_mask_shapes_binned(int nx, int ny, int 
 }
 
 // out[0] = 1 if any byte of the raster is non-zero (n bytes; 4 at a time, then the tail)
-__global__ __launch_bounds__(256) void k_mask_any(const uint8_t* __restrict__ m, size_t n, unsigned* __restrict__ out) {
+static __global__ __launch_bounds__(256) void k_mask_any(const uint8_t* __restrict__ m, size_t n, unsigned* __restrict__ out) {
     const size_t n4 = n >> 2;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     unsigned any = 0;
@@ -1833,7 +1836,7 @@ __global__ __launch_bounds__(256) void k_mask_any(const uint8_t* __restrict__ m,
     if (any) out[0] = 1;
 }
 
-__global__ __launch_bounds__(256) void k_mask_normalise(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n) {
+static __global__ __launch_bounds__(256) void k_mask_normalise(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += stride) out[c] = in[c] ? 1 : 0;
 }
@@ -1849,7 +1852,7 @@ __device__ __forceinline__ void lazy_umax(unsigned* p, unsigned v) {
 }
 
 // out[0] = max top z1q, out[1] = max len (len must be current, see k_relen)
-__global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restrict__ out) {
+static __global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restrict__ out) {
     unsigned mq = 0, ml = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
@@ -1867,7 +1870,7 @@ __global__ __launch_bounds__(256) void k_max_top(GridView g, unsigned* __restric
 }
 
 // split form: out[0] = max top z1q from the top stream alone (an empty column's top is 0)
-__global__ __launch_bounds__(256) void k_max_top_split(GridView g, unsigned* __restrict__ out) {
+static __global__ __launch_bounds__(256) void k_max_top_split(GridView g, unsigned* __restrict__ out) {
     unsigned mq = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
@@ -1881,7 +1884,7 @@ __global__ __launch_bounds__(256) void k_max_top_split(GridView g, unsigned* __r
 
 // whole form: top[c] = the column's top interval (0: empty), so that a lateral step can stage the OLD
 // heights from the top stream while it rewrites the planes in place
-__global__ __launch_bounds__(256) void k_snapshot_tops(GridView g) {
+static __global__ __launch_bounds__(256) void k_snapshot_tops(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
@@ -1890,7 +1893,7 @@ __global__ __launch_bounds__(256) void k_snapshot_tops(GridView g) {
 }
 
 // split form: len[c] recounted from the chain (the 4-columns-per-thread kernels do not maintain it)
-__global__ __launch_bounds__(256) void k_relen(GridView g) {
+static __global__ __launch_bounds__(256) void k_relen(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         g.len[c] = (uint8_t)chain_length(g, c);
@@ -1898,7 +1901,7 @@ __global__ __launch_bounds__(256) void k_relen(GridView g) {
 }
 
 // whole form: out[0] = max number of layers (gap intervals not counted), out[1] = max len
-__global__ __launch_bounds__(256) void k_max_layers(GridView g, unsigned* __restrict__ out) {
+static __global__ __launch_bounds__(256) void k_max_layers(GridView g, unsigned* __restrict__ out) {
     unsigned mw = 0, ml = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
@@ -1935,7 +1938,7 @@ __device__ __forceinline__ unsigned long long checksum_term(unsigned long long h
 // A lane walks CHECKSUM_U columns side by side (a block takes CHECKSUM_U runs of 256 neighbouring columns), so that
 // CHECKSUM_U dependent loads are in flight per lane instead of one; every load of a wave is of neighbouring columns.
 constexpr int CHECKSUM_U = 8;
-__global__ __launch_bounds__(256) void k_checksum(GridView g, unsigned long long* __restrict__ out) {
+static __global__ __launch_bounds__(256) void k_checksum(GridView g, unsigned long long* __restrict__ out) {
     constexpr int U = CHECKSUM_U;
     unsigned long long sum = 0;
     const size_t span = (size_t)U * blockDim.x;
@@ -1995,7 +1998,7 @@ __global__ __launch_bounds__(256) void k_checksum(GridView g, unsigned long long
 // CMP (script_columngrid.js:747-859)
 // ------------------------------------------------------------------------------------------
 // out[0] = max z1q over every layer of material stopMat (0 when there is none), out[1] = 1 if any
-__global__ __launch_bounds__(256) void k_cmp_stopper_top(GridView g, int stopMat, unsigned* __restrict__ out) {
+static __global__ __launch_bounds__(256) void k_cmp_stopper_top(GridView g, int stopMat, unsigned* __restrict__ out) {
     unsigned mq = 0, any = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
@@ -2010,7 +2013,7 @@ __global__ __launch_bounds__(256) void k_cmp_stopper_top(GridView g, int stopMat
 }
 
 // per-column truncation to limit = max(targetZ, z1 of the column's lowest stopper layer)
-__global__ __launch_bounds__(256) void k_cmp_apply(GridView g, double targetZ, int stopMat) {
+static __global__ __launch_bounds__(256) void k_cmp_apply(GridView g, double targetZ, int stopMat) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         int l = g.len[c];
@@ -2095,7 +2098,7 @@ __device__ __forceinline__ bool layer_exposed(const GridView& g, const Ghost& gh
 
 // cand[c] = 1 while column c still has an unmarked node of matId: the sweeps skip the others
 // after reading one byte.
-__global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand) {
+static __global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
@@ -2124,7 +2127,7 @@ __global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh, int ma
 // one column per pass along a row, and the tiles that do change cost up to a tile's width in passes: 2x slower overall.)
 // before: the flag word of the sweep launched just before this one on the same stream, or null.  A sweep that changed
 // nothing has found the fixpoint, so the sweeps queued behind it in the same batch return at once.
-__global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand, int reverse, int* __restrict__ changed,
+static __global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand, int reverse, int* __restrict__ changed,
                                                      const int* __restrict__ before) {
     if (before && __hip_atomic_load(before, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -2166,7 +2169,7 @@ __global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh, int m
 
 // Boundary rows of a slab as ghost messages: len[ny] (padded to a multiple of 4 bytes), then
 // rec[planes][ny].  send_lower = row 0, send_upper = row nx-1.
-__global__ __launch_bounds__(256) void k_ghost_pack(GridView g, int planes, uint8_t* __restrict__ send_lower, uint8_t* __restrict__ send_upper) {
+static __global__ __launch_bounds__(256) void k_ghost_pack(GridView g, int planes, uint8_t* __restrict__ send_lower, uint8_t* __restrict__ send_upper) {
     const size_t lenb = ((size_t)g.ny + 3) & ~(size_t)3;
     const size_t n = (size_t)g.ny * (planes + 1);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -2184,7 +2187,7 @@ __global__ __launch_bounds__(256) void k_ghost_pack(GridView g, int planes, uint
 // removal + compaction (cg1:970-999): marked layers go; one in the middle of a column leaves a
 // gap interval (adjacent gaps merge, a gap on top goes too).  flags[2] = a gap remains somewhere,
 // flags[1] = a cavity layer (material 2) remains somewhere.
-__global__ __launch_bounds__(256) void k_strip_compact(GridView g, int* __restrict__ flags) {
+static __global__ __launch_bounds__(256) void k_strip_compact(GridView g, int* __restrict__ flags) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     int gap = 0, cav = 0;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
@@ -2216,7 +2219,7 @@ __global__ __launch_bounds__(256) void k_strip_compact(GridView g, int* __restri
 // identify_cavity step 1 (cg2:23-71): every gap becomes a cavity layer (material 2) and every
 // column lower than the highest one gets a cavity layer up to that height.  The host has made
 // sure that a plane is free above every column.
-__global__ __launch_bounds__(256) void k_cavity_fill(GridView g, unsigned hmax_q) {
+static __global__ __launch_bounds__(256) void k_cavity_fill(GridView g, unsigned hmax_q) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];
@@ -2237,7 +2240,7 @@ __global__ __launch_bounds__(256) void k_cavity_fill(GridView g, unsigned hmax_q
 // op 0 appends (mat, z0q, z1q): a start above the column top takes a gap interval of its own,
 // a start below it cannot be held (flags[1]); flags[0] asks the host for more planes.
 // op 1 drops the top layer, and with it a gap it was resting on.
-__global__ void k_edit_column(GridView g, size_t c, int op, int mat, unsigned z0q, unsigned z1q, int* flags) {
+static __global__ void k_edit_column(GridView g, size_t c, int op, int mat, unsigned z0q, unsigned z1q, int* flags) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     int l = g.len[c];
     if (op == 0) {
@@ -2323,7 +2326,7 @@ __device__ __forceinline__ int gather_column(const GridView& g, size_t c, int co
 // reference layout with stride L: omat[s*L+k], ozp[2*(s*L+k)+{0,1}], olen[s]; gaps are skipped,
 // slots at and above the layer count are zero.
 // count_chain: the grid is in split form and len[] is behind (see k_relen): count the chain instead.
-__global__ __launch_bounds__(256) void k_gather_columns(GridView g, size_t col0, size_t col_stride, size_t ncols, int L, int count_chain,
+static __global__ __launch_bounds__(256) void k_gather_columns(GridView g, size_t col0, size_t col_stride, size_t ncols, int L, int count_chain,
                                                         uint8_t* __restrict__ omat, uint16_t* __restrict__ ozp, uint8_t* __restrict__ olen) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < ncols; s += stride) {
@@ -2335,7 +2338,7 @@ __global__ __launch_bounds__(256) void k_gather_columns(GridView g, size_t col0,
 // `count` cross-sections in one launch: slice s is row index[s] (axis 0: columns index[s]*ny + p) or
 // column index[s] (axis 1: columns p*ny + index[s]), p < line; output as in k_gather_columns, slice
 // after slice.
-__global__ __launch_bounds__(256) void k_gather_slices(GridView g, int axis, const int32_t* __restrict__ index, int count, size_t line, int L,
+static __global__ __launch_bounds__(256) void k_gather_slices(GridView g, int axis, const int32_t* __restrict__ index, int count, size_t line, int L,
                                                        int count_chain, uint8_t* __restrict__ omat, uint16_t* __restrict__ ozp, uint8_t* __restrict__ olen) {
     const size_t total = (size_t)count * line;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -2350,7 +2353,7 @@ __global__ __launch_bounds__(256) void k_gather_slices(GridView g, int axis, con
 // top of the one below becomes a gap interval + the layer.  flags[2]: some column has a gap;
 // flags[3]: a column needs more planes than provisioned (the largest need); flags[1]: a layer
 // starts below the top of the one under it (cannot be represented).
-__global__ __launch_bounds__(256) void k_scatter_columns(GridView g, size_t col0, size_t ncols, int L,
+static __global__ __launch_bounds__(256) void k_scatter_columns(GridView g, size_t col0, size_t ncols, int L,
                                                          const uint8_t* __restrict__ imat, const uint16_t* __restrict__ izp,
                                                          const uint8_t* __restrict__ ilen, int* __restrict__ flags) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -2380,7 +2383,7 @@ __global__ __launch_bounds__(256) void k_scatter_columns(GridView g, size_t col0
 // ------------------------------------------------------------------------------------------
 // split -> whole: the chain that starts at the top is laid out by index in the planes, links cleared.  A
 // column's planes are its own, so it is read completely before anything of it is written.
-__global__ __launch_bounds__(256) void k_demote(GridView g) {
+static __global__ __launch_bounds__(256) void k_demote(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = min((int)g.len[c], LNK_NONE + 1);     // (the split form holds no taller column)
@@ -2393,7 +2396,7 @@ __global__ __launch_bounds__(256) void k_demote(GridView g) {
 
 // whole -> split: interval k stays in plane k and gets the link to plane k-1; the top interval is
 // copied to the top stream.  The host has checked that no column is taller than LNK_NONE + 1.
-__global__ __launch_bounds__(256) void k_promote(GridView g) {
+static __global__ __launch_bounds__(256) void k_promote(GridView g) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
         const int l = g.len[c];

@@ -1,0 +1,24 @@
+// k_stencil_stream instantiations for the radii CG_RLO..CG_RHI (one translation unit per pair of radii).
+#include "cg_launch.h"
+
+#define CG_CAT2(a, b) a##b
+#define CG_CAT(a, b) CG_CAT2(a, b)
+
+namespace cgk {
+
+template <int RR>
+static void stream_one(bool etch, bool msg, bool masked, unsigned blocks, hipStream_t s, const StreamArgs& a) {
+#define L(E, M, K) hipLaunchKernelGGL((k_stencil_stream<RR, E, M, K>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.Rimg, \
+                                      a.halo_lo, a.halo_up, a.d_quad, a.so, a.flags, a.stats)
+    if (etch) { if (msg) { if (masked) L(true, true, true); else L(true, true, false); } else { if (masked) L(true, false, true); else L(true, false, false); } }
+    else { if (msg) { if (masked) L(false, true, true); else L(false, true, false); } else { if (masked) L(false, false, true); else L(false, false, false); } }
+#undef L
+}
+
+bool CG_CAT(launch_stream_r, CG_RLO)(int Re, bool etch, bool msg, bool masked, unsigned blocks, hipStream_t s, const StreamArgs& a) {
+    if (Re == CG_RLO) { stream_one<CG_RLO>(etch, msg, masked, blocks, s, a); return true; }
+    if (Re == CG_RHI) { stream_one<CG_RHI>(etch, msg, masked, blocks, s, a); return true; }
+    return false;
+}
+
+}  // namespace cgk

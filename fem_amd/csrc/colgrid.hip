@@ -11,12 +11,14 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/colgrid.h"
 #include "cg_kernels.hip.h"
 #include "cg_interval_kernels.hip.h"
+#include "cg_launch.h"
 
 using namespace cgk;
 
@@ -47,6 +49,11 @@ static int stream_tile_rows() {
 namespace {
 
 thread_local std::string t_create_error;
+
+// device address of the index array of cg_slices_noalloc on every GPU a handle has been created on (see there)
+constexpr int MAX_DEVICES = 64;
+int32_t* g_scratch_ptr[MAX_DEVICES] = {nullptr};
+std::mutex g_scratch_mutex;
 
 // One cached conformal kernel (script_columngrid.js:324-357): radius, the thickness it was
 // built for (the reference reuses it as `baseAdd` on a cache hit) and its taps on the device.
@@ -193,6 +200,9 @@ struct ProfScope {
 
 int materialize(cg_grid* g);
 int flush_vertical(cg_grid* g);
+}
+static int scratch_resolve(cg_grid* g);
+namespace {
 #define NEED_H0(g)                                                                            \
     do { if (!(g)) return fail(nullptr, CG_ERR_ARG, "null handle");                           \
          hipError_t e__ = hipSetDevice((g)->device);                                          \
@@ -711,64 +721,26 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
         if (getenv("CG_STREAM_NOF32")) { sopt.deq_f32 = 0; sopt.skip_init = 0; sopt.grow_f32 = 0; }
         sopt.a00 = K->quad.empty() ? 0.f : K->quad[0];
         sopt.fast_rows = (etch && !K->quad.empty() && K->quad[0] != -INFINITY && !getenv("CG_STREAM_NOFAST")) ? 1 : 0;
-#define STREAM_L(RR, E, M, K_, BAND)                                                                           \
-    do {                                                                                                       \
-        gv.tile_i0 = (BAND).t0; gv.tile_in = (BAND).n; gv.sup_i = 1; gv.sup_j = 1;                             \
-        const dim3 gridS((unsigned)(((long)(BAND).n * tiles_j + 7) / 8 * 8));                                  \
-        hipLaunchKernelGGL((k_stencil_stream<RR, E, M, K_>), gridS, dim3(64), 0, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
-                           K->d_quad, sopt, g->d_flags, g->d_stats);                                           \
-    } while (0)
-#define STREAM(RR, E, K_)                                                                                      \
-    do {                                                                                                       \
-        if (part != PART_BOUNDARY) for (int b_ = 0; b_ < n_int; b_++) STREAM_L(RR, E, false, K_, bi[b_]);      \
-        if (part != PART_INTERIOR) for (int b_ = 0; b_ < n_bnd; b_++) STREAM_L(RR, E, true, K_, bb[b_]);       \
-    } while (0)
-#define STREAM_ES(RR)                                                                                          \
-    do {                                                                                                       \
-        if (etch) { if (mask) STREAM(RR, true, true); else STREAM(RR, true, false); }                          \
-        else { if (mask) STREAM(RR, false, true); else STREAM(RR, false, false); }                             \
-    } while (0)
-        switch (K->Re) {
-        case 1: STREAM_ES(1); break; case 2: STREAM_ES(2); break; case 3: STREAM_ES(3); break; case 4: STREAM_ES(4); break;
-        case 5: STREAM_ES(5); break; case 6: STREAM_ES(6); break; case 7: STREAM_ES(7); break; default: STREAM_ES(8); break;
-        }
-#undef STREAM_ES
-#undef STREAM
-#undef STREAM_L
+        StreamArgs sa{gv, mask, mat, t_eff, R, halo_lo, halo_up, K->d_quad, sopt, g->d_flags, g->d_stats};
+        const auto go = [&](const Band& band, bool msg) {
+            sa.gv.tile_i0 = band.t0; sa.gv.tile_in = band.n; sa.gv.sup_i = 1; sa.gv.sup_j = 1;
+            launch_stream(K->Re, etch, msg, mask != nullptr, (unsigned)(((long)band.n * tiles_j + 7) / 8 * 8), g->stream, sa);
+        };
+        if (part != PART_BOUNDARY) for (int b_ = 0; b_ < n_int; b_++) go(bi[b_], false);
+        if (part != PART_INTERIOR) for (int b_ = 0; b_ < n_bnd; b_++) go(bb[b_], true);
         HIPCHK(g, hipGetLastError());
         return CG_OK;
     }
     if (sym) {
         g->len_valid = false;
         const int tjs = sym_tile_cols(K->Re);
-#define SYM(RR, TT, E, S)                                                                                      \
-    do {                                                                                                       \
-        AddTab<RR> tab; memcpy(tab.a, K->quad.data(), sizeof tab.a);                                           \
-        for (int du_ = 0; du_ <= RR; du_++) {                                                                  \
-            tab.lim[du_] = -1;                                                                                 \
-            for (int dv_ = 0; dv_ <= RR; dv_++) if (tab.a[du_ * (RR + 1) + dv_] != -INFINITY) tab.lim[du_] = dv_; \
-        }                                                                                                      \
-        const int tis = 1024 / TT * sym_passes(RR);                                                            \
-        const int nb = stencil_bands(g->nx, tis, R, halo_lo != nullptr, halo_up != nullptr, part, bands);      \
-        for (int b_ = 0; b_ < nb; b_++) {                                                                      \
-            const dim3 gridS(sup_grid(gv, bands[b_].t0, bands[b_].n, (g->ny + TT - 1) / TT));                  \
-            hipLaunchKernelGGL((k_stencil_sym<RR, TT, E, S>), gridS, blk, 0, g->stream, gv, mask, mat, t_eff, R, halo_lo, halo_up, \
-                               tab, K->d_taps64_sym, K->ntaps64_sym, g->d_flags, g->d_stats);                  \
-        }                                                                                                      \
-    } while (0)
-#define SYM_T(RR, E, S) do { if (tjs == 64) SYM(RR, 64, E, S); else if (tjs == 128) SYM(RR, 128, E, S); else SYM(RR, 256, E, S); } while (0)
-#define SYM_ES(RR)                                                                                             \
-    do {                                                                                                       \
-        if (etch) { if (g->stats_on) SYM_T(RR, true, true); else SYM_T(RR, true, false); }                     \
-        else { if (g->stats_on) SYM_T(RR, false, true); else SYM_T(RR, false, false); }                        \
-    } while (0)
-        switch (K->Re) {
-        case 1: SYM_ES(1); break; case 2: SYM_ES(2); break; case 3: SYM_ES(3); break; case 4: SYM_ES(4); break;
-        case 5: SYM_ES(5); break; case 6: SYM_ES(6); break; case 7: SYM_ES(7); break; default: SYM_ES(8); break;
+        const int tis = 1024 / tjs * sym_passes(K->Re);
+        const int nb = stencil_bands(g->nx, tis, R, halo_lo != nullptr, halo_up != nullptr, part, bands);
+        SymArgs ya{gv, mask, mat, t_eff, R, halo_lo, halo_up, K->quad.data(), K->d_taps64_sym, K->ntaps64_sym, g->d_flags, g->d_stats};
+        for (int b_ = 0; b_ < nb; b_++) {
+            const unsigned blocks = sup_grid(ya.gv, bands[b_].t0, bands[b_].n, (g->ny + tjs - 1) / tjs);
+            launch_sym(K->Re, tjs, etch, g->stats_on, blocks, g->stream, ya);
         }
-#undef SYM_ES
-#undef SYM_T
-#undef SYM
         HIPCHK(g, hipGetLastError());
         return CG_OK;
     }
@@ -966,7 +938,10 @@ static VertOpts vert_opts(cg_grid* g, double t, bool etch) {
     VertOpts none{-1, -1, -1, -1};
     if (off || !(t > 0) || !(g->zscale > 1e-6) || !(t / g->zscale < 60000.0)) return none;
     for (const auto& e : g->vopt_cache) if (e.t == t && e.etch == etch) return e.vo;
-    const double zs = g->zscale, margin = 1e-10;
+    // thick = q1*zs - q0*zs carries the rounding of two products of up to 65535*zs each: the thresholds must stay
+    // clear of the reference's 1e-9 by more than that, whatever the step size
+    const double zs = g->zscale, margin = std::max(1e-10, 4.0 * 65535.0 * zs * 2.220446049250313e-16);
+    if (margin > 2.5e-10) return none;                         // (steps above ~4 nm: the double form decides)
     VertOpts vo = none;
     if (!etch) {
         const int K = (int)quantz_host(0.0 * zs + t, zs);
@@ -1143,7 +1118,8 @@ int cg_create_slab(int nx_global, int ny, int i0, int nx_local, double dx, doubl
         HIPCHK(g, hipMemset(g->d_flags, 0, 4 * sizeof(int)));
         HIPCHK(g, hipMemset(g->d_stats, 0, CG_NSTAT * sizeof(unsigned long long)));
         HIPCHK(g, hipEventCreate(&g->ev0)); HIPCHK(g, hipEventCreate(&g->ev1));
-        int r = alloc_planes(g, lmax); if (r) return r;
+        int r = scratch_resolve(g); if (r) return r;
+        r = alloc_planes(g, lmax); if (r) return r;
         g->lmax_vis = lmax;
         r = zero_planes(g); if (r) return r;
         HIPCHK(g, hipStreamSynchronize(g->stream));
@@ -1195,7 +1171,8 @@ int cg_destroy(cg_grid* g) {
 }
 
 int cg_reset(cg_grid* g, int lmax_init) {
-    NEED_H(g);
+    NEED_H0(g);
+    g->vq.clear();                       // queued vertical steps would be wiped out anyway: dropped, not launched
     int lmax = next_pow2(lmax_init > 0 ? lmax_init : g->lmax_vis);
     if (lmax > 256) lmax = 256;
     g->pend.active = false;
@@ -1212,7 +1189,7 @@ int cg_set_plane_budget(cg_grid* g, int max_planes) {
     return CG_OK;
 }
 
-int cg_clear(cg_grid* g) { NEED_H(g); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
+int cg_clear(cg_grid* g) { NEED_H0(g); g->vq.clear(); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
 
 int cg_get_info(const cg_grid* g, cg_info* o) {
     if (!g || !o) return CG_ERR_ARG;
@@ -1441,10 +1418,16 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     bool ok; const uint8_t* mask = mask_ptr(g, mask_id, &ok);
     if (!ok) return fail(g, CG_ERR_ARG, "unknown mask id %d", mask_id);
     if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
-    // a thickness / conformality that is not a number reaches the grid as 0 (Number(x) || 0, rt:154-156)
+    // a thickness that is not a number never passes "thickness <= 0" in the runtime's guard nor "t <= 0" in the grid
+    // (rt:159, cg1:437, 600: both comparisons are false for NaN), and every height it then produces is NaN, which a
+    // Uint16Array stores as 0: columns collapse.  Nothing a caller can want; taken as "no thickness", a no-op.
     const double t = std::isnan(thickness) ? 0.0 : std::max(0.0, thickness);
     if (!(t > 0)) return CG_OK;                                           // cg1:437, 600
-    const double S = std::isnan(conformality) ? 0.0 : std::max(0.0, std::min(1.0, conformality));   // cg1:440, 603
+    // A conformality that is not a number passes the runtime's typeof test (rt:156) and the clamp (cg1:440, 603)
+    // unchanged, fails "latRange < min(dx, dy)" and takes the lateral path with a kernel that has no taps:
+    // not a step of the reference's model, refused.
+    if (std::isnan(conformality)) return fail(g, CG_ERR_ARG, "conformality is not a number");
+    const double S = std::max(0.0, std::min(1.0, conformality));          // cg1:440, 603
     const double latRange = t * S;
     // a vertical step joins the queue of vertical steps when the fused kernel can take it; anything else first
     // launches what is queued
@@ -1515,6 +1498,16 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     g->pend.has_lower = has_lower != 0; g->pend.has_upper = has_upper != 0;
     g->pend.interior_done = false; g->pend.may_overflow = false; g->pend.P = -1;
     if (radius_rows) *radius_rows = R;
+    return CG_OK;
+}
+
+int cg_kernel_cache_touch(cg_grid* g, double thickness, double conformality) {
+    NEED_H0(g);
+    if (std::isnan(conformality)) return fail(g, CG_ERR_ARG, "conformality is not a number");
+    const double t = std::isnan(thickness) ? 0.0 : std::max(0.0, thickness);
+    const double S = std::max(0.0, std::min(1.0, conformality));
+    if (!(t > 0) || t * S < std::min(g->dx, g->dy)) return CG_OK;         // cg1:437, 445: such a step never asks for a kernel
+    (void)get_kernel(g, t, S);
     return CG_OK;
 }
 
@@ -2211,8 +2204,9 @@ int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
 }
 
 int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8_t* len, int lmax) {
-    NEED_H(g);
+    NEED_H0(g);
     if (!mat || !zpair || !len || lmax < 1 || lmax > 256) return fail(g, CG_ERR_ARG, "bad upload arguments (lmax=%d)", lmax);
+    g->vq.clear();                       // every column is replaced: queued vertical steps are dropped, not launched
     g->pend.active = false;
     HIPCHK(g, hipStreamSynchronize(g->stream));
     if (lmax > g->lmax) { int rc = grow_planes(g, lmax - g->lmax); if (rc) return rc; }
@@ -2271,9 +2265,10 @@ int cg_snapshot_save(cg_grid* g, int slot) {
 }
 
 int cg_snapshot_load(cg_grid* g, int slot) {
-    NEED_H(g);
+    NEED_H0(g);
     auto it = g->snaps.find(slot);
     if (it == g->snaps.end()) return fail(g, CG_ERR_ARG, "no snapshot in slot %d", slot);
+    g->vq.clear();                       // the grid is replaced: queued vertical steps are dropped, not launched
     const Snapshot& s = it->second;
     g->pend.active = false;
     if (s.planes > g->lmax) { int rc = grow_planes(g, (s.planes - g->lmax + 15) / 16 * 16); if (rc) return rc; }
@@ -2346,27 +2341,23 @@ int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count, void
 // The index list of cg_slices_noalloc is staged in this array instead of a buffer the library
 // allocates.  Every GPU holds its own copy at its own address until the process ends; all handles on
 // one GPU share that copy.  In host code the name `scratch` is only a stand-in for the symbol: the
-// device address is looked up once per device (scratch_on_device) and that pointer is what copies
+// device address is looked up once per device (scratch_resolve, at handle creation) and that pointer is what copies
 // and kernels get.
 static __device__ __align__(256) int32_t scratch[CG_SLICES_NOALLOC_MAX];
 
-namespace {
-constexpr int MAX_DEVICES = 64;
-int32_t* g_scratch_ptr[MAX_DEVICES] = {nullptr};
-
-// device address of `scratch` on the handle's device (which the caller has made current)
-int scratch_on_device(cg_grid* g, int32_t** out) {
-    if (g->device < 0 || g->device >= MAX_DEVICES) return fail(g, CG_ERR_UNSUPPORTED, "device ordinal %d beyond %d", g->device, MAX_DEVICES);
-    if (!g_scratch_ptr[g->device]) {
-        int32_t* p = nullptr;
-        HIPCHK(g, hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
-        if (!p) return fail(g, CG_ERR_HIP, "hipGetSymbolAddress gave a null address");
-        g_scratch_ptr[g->device] = p;
-    }
-    *out = g_scratch_ptr[g->device];
+// Looks up the device address of `scratch` on the current device (once per device and process, under a lock: the
+// array is shared by every handle and thread on that GPU).  Called from cg_create_slab, so that cg_slices_noalloc
+// itself only reads the table.
+static int scratch_resolve(cg_grid* g) {
+    if (g->device < 0 || g->device >= MAX_DEVICES) return CG_OK;          // cg_slices_noalloc refuses such a device
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[g->device]) return CG_OK;
+    int32_t* p = nullptr;
+    HIPCHK(g, hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(g, CG_ERR_HIP, "hipGetSymbolAddress gave a null address");
+    g_scratch_ptr[g->device] = p;
     return CG_OK;
 }
-}  // namespace
 
 int cg_slices_noalloc(cg_grid* g, int axis, const int32_t* index, int count, void* d_mat, void* d_zpair, void* d_len) {
     NEED(g);
@@ -2378,8 +2369,9 @@ int cg_slices_noalloc(cg_grid* g, int axis, const int32_t* index, int count, voi
     const int lim = axis == 0 ? g->nx : g->ny;
     for (int s = 0; s < count; s++)
         if (index[s] < 0 || index[s] >= lim) return fail(g, CG_ERR_ARG, "slice index %d outside [0,%d)", index[s], lim);
-    int32_t* d_idx = nullptr;
-    { int rc = scratch_on_device(g, &d_idx); if (rc) return rc; }
+    if (g->device < 0 || g->device >= MAX_DEVICES) return fail(g, CG_ERR_UNSUPPORTED, "device ordinal %d beyond %d", g->device, MAX_DEVICES);
+    int32_t* const d_idx = g_scratch_ptr[g->device];                       // resolved when the handle was created
+    if (!d_idx) return fail(g, CG_ERR_STATE, "the index array of this device was never resolved");
     // only the first `count` entries are rewritten; the kernel reads no others
     HIPCHK(g, hipMemcpyAsync(d_idx, index, (size_t)count * sizeof(int32_t), hipMemcpyHostToDevice, g->stream));
     hipLaunchKernelGGL(k_gather_slices, dim3(blocks_for(line * count)), dim3(256), 0, g->stream, view(g), axis, d_idx, count, line, g->lmax_vis,

@@ -93,7 +93,6 @@ class SlabGrid:
         self._halo = None
         self._rows = 0
         self._gaps_anywhere = None      # "some slab may hold a gap or a cavity": None = ask the ranks again
-        self._mask_any = {}             # mask id -> "open somewhere in the domain" (all-reduced once per mask)
         self.halo_bytes = 0             # bytes this rank has sent in halo exchanges of lateral steps
         self.swap_seconds = 0.0         # host time between the start and the completion of those exchanges
         self.stream = None
@@ -177,19 +176,32 @@ class SlabGrid:
             self.comm.swap(*[t[:nbytes] for t in self._ghost])
 
     def _open_somewhere(self, mask):
-        """Does the mask open a cell anywhere in the domain?  (One all-reduce per mask; rasters never change.)"""
+        """Does the mask open a cell anywhere in the domain?  One all-reduce per mask OBJECT (rasters never change):
+        the answer is kept on the object itself, not under its id -- the library hands the id of a destroyed mask
+        out again, and the next raster in that slot must not inherit the answer."""
         if mask is None or not hasattr(self.grid, "mask_any_open"):
             return True
-        key = getattr(mask, "id", id(mask))
-        if key not in self._mask_any:
-            self._mask_any[key] = bool(self._reduce_max([1 if self.grid.mask_any_open(mask) else 0])[0])
-        return self._mask_any[key]
+        try:
+            return mask._open_somewhere
+        except AttributeError:
+            pass
+        ans = bool(self._reduce_max([1 if self.grid.mask_any_open(mask) else 0])[0])
+        try:
+            mask._open_somewhere = ans
+        except AttributeError:            # a mask type that takes no attributes (a numpy raster of the CPU stand-in): ask every time
+            pass
+        return ans
 
     # ---- the reference's step names
     def deposit_general(self, mask, matId, thickness, conformality=1.0):
         lateral = self._radius(thickness, conformality) > 0
         if self.world > 1 and lateral and not self._open_somewhere(mask):
-            return                                       # no open cell in the whole domain: script_columngrid.js:485
+            # no open cell in the whole domain: script_columngrid.js:485 returns -- after line 470 has put the
+            # step's kernel into the kernel cache, which a later step with a colliding key will find
+            touch = getattr(self.grid, "kernel_cache_touch", None)
+            if touch is not None and float(thickness) > 0:
+                touch(thickness, conformality)
+            return
         if matId == 2:
             self._gaps_anywhere = None                   # material 2 is what identify_cavity strips
         self._step(STENCIL_DEPOSIT, mask, matId, thickness, conformality)

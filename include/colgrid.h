@@ -20,6 +20,12 @@
  * Vertical steps (cg_deposit_general / cg_etch_general / cg_stencil_begin with t*S < min(dx, dy))
  * are queued in the handle, up to six, and launched together by the next entry point that is not
  * such a step (cg_sync included): same results, one pass over the columns instead of one per step.
+ * Consequences for a caller that brings its own stream (cg_set_stream): when such a call returns,
+ * nothing of it may be on the stream yet -- an event recorded, or dependent work enqueued, right
+ * after it does not wait for the step.  cg_sync, cg_get_stream or any entry point other than a
+ * vertical step puts the queued steps on the stream first; a launch error of a queued step is
+ * reported by that later call.  cg_reset, cg_clear, cg_upload and cg_snapshot_load replace every
+ * column: steps still queued are dropped, not launched.
  *
  * The comment above each declaration names the reference interface it stands in for.
  * "cg1/cg2/rt/sl" = template/script_columngrid.js, script_columngrid2.js,
@@ -154,6 +160,12 @@ int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes,
  * returns untouched -- no identify_cavity either -- when no cell of the domain is open (cg1:474-485);
  * an undivided grid checks that itself, a slab driver asks every slab and combines the answers. */
 int cg_mask_any_open(cg_grid* g, int mask_id, int* any);
+
+/* _getConformalKernelArray's cache (cg1:324-357, 32 entries, FIFO, keyed by t, S, dx, dy truncated to 1e-3) gets
+ * its entry for a lateral step of this thickness and conformality, as deposit_general creates it BEFORE it finds
+ * that the mask opens no cell and returns (cg1:470 vs 485).  For a slab driver that skips such a step on every
+ * slab: a later step whose key collides must find the same cached kernel as on an undivided grid. */
+int cg_kernel_cache_touch(cg_grid* g, double thickness, double conformality);
 
 int cg_mask_download(cg_grid* g, int mask_id, uint8_t* host_out, size_t n);
 int cg_mask_destroy(cg_grid* g, int mask_id);
@@ -345,15 +357,18 @@ int cg_slices(cg_grid* g, int axis, const int32_t* index, int count,
 int cg_slices_device(cg_grid* g, int axis, const int32_t* index, int count,
                      void** d_mat, void** d_zpair, void** d_len);
 
-/* The same cross-sections for callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
- * reference.  The caller owns the outputs, all in DEVICE memory: d_mat count*line_cols*lmax bytes,
- * d_zpair 4 times that, d_len count*line_cols bytes (line_cols = ny for axis 0, nx for axis 1;
- * lmax = cg_info.lmax).  index is a host array.  The call allocates and frees nothing: the index list
- * is staged in a fixed array of CG_SLICES_NOALLOC_MAX entries (16 KiB) that lives in the library's
- * device image, one copy per GPU, shared by every handle on that GPU.  count beyond the maximum is
- * refused with CG_ERR_ARG.  Work is enqueued on the handle's stream and not waited for; two calls that
- * overlap in time on one GPU (two handles on different streams, two threads) race on the shared array. */
+/* The same cross-sections for callers that cannot allocate device memory: tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  The caller owns the
+ * outputs, all in DEVICE memory: d_mat count*line_cols*lmax bytes (4-byte aligned), d_zpair 4 times
+ * that (16-byte aligned), d_len count*line_cols bytes (line_cols = ny for axis 0, nx for axis 1;
+ * lmax = cg_info.lmax); hipMalloc'ed buffers satisfy the alignments.  index is a host array.  The
+ * call calls no hipMalloc / hipFree: the index list is staged in a fixed array of
+ * CG_SLICES_NOALLOC_MAX entries (16 KiB) that lives in the library's device image, one copy per GPU,
+ * shared by every handle on that GPU (its address is looked up when a handle is created).  count
+ * beyond the maximum is refused with CG_ERR_ARG.  Work is enqueued on the handle's stream and not
+ * waited for, but the call is NOT meant for stream capture: it first launches queued vertical steps
+ * and copies the index list from the caller's (pageable) host memory.  Two calls that overlap in time
+ * on one GPU (two handles on different streams, two threads) race on the shared array. */
 #define CG_SLICES_NOALLOC_MAX 4096
 int cg_slices_noalloc(cg_grid* g, int axis, const int32_t* index, int count,
                       void* d_mat, void* d_zpair, void* d_len);

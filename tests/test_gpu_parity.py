@@ -1082,3 +1082,59 @@ def test_slab_ald_refuses_a_slab_thinner_than_the_coat_reach():
     with pytest.raises(Exception, match="reaches"):
         g.ald_collect_seeds_slab(7.0, 100, 4, ghost.data_ptr(), ghost.data_ptr())
     g.close()
+
+
+def test_slab_driver_when_a_mask_id_is_handed_out_again():
+    """A mask that opens no cell anywhere makes a lateral deposit return early -- after the reference has put the
+    step's kernel into its kernel cache (script_columngrid.js:470 vs 485).  The mask is then destroyed and the next
+    raster, an open one, gets its id: the slab driver must ask again whether it is open, and the next lateral
+    deposit, whose cache key collides with the skipped step's (thicknesses closer than 1e-3), must find that
+    step's kernel, as on the undivided grid."""
+    import threading
+    import torch
+    fem = _engine()
+    from fem_amd.slabs import SlabGrid
+    parts, nxl, ny = 2, 24, 40
+    nxg = nxl * parts
+    o = OracleGrid(2.0 * nxg, 2.0 * ny, 2.0, 2.0)
+    closed = np.zeros(nxg * ny, np.uint8)
+    rng = np.random.RandomState(11)
+    opened = (rng.rand(nxg * ny) < 0.7).astype(np.uint8)
+    want = []
+    o.deposit_general(None, 3, 20, 0); want.append(o.checksum())
+    o.deposit_general(closed, 4, 6.0004, 1.0); want.append(o.checksum())
+    o.deposit_general(opened, 5, 6.0001, 1.0); want.append(o.checksum())
+    o.etch_general(opened, 5, 3, 1.0); want.append(o.checksum())
+    assert want[0] == want[1] != want[2]
+    comm = _ThreadComm(parts)
+    errors = []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            g = fem.ColumnGrid(dx=2.0, dy=2.0, slab=(nxg, ny, rank * nxl, nxl))
+            mine = lambda r: np.ascontiguousarray(r.reshape(nxg, ny)[rank * nxl:(rank + 1) * nxl]).reshape(-1)
+            slab = SlabGrid(g, rank, parts, device=torch.device("cuda", 0), ny=ny, halo_rows=4, comm=comm.view(rank))
+            got = []
+            slab.deposit_general(None, 3, 20, 0); got.append(slab.checksum())
+            m0 = g.mask_from_raster(mine(closed))
+            slab.deposit_general(m0, 4, 6.0004, 1.0); got.append(slab.checksum())
+            old_id = m0.id
+            m0.destroy()
+            m1 = g.mask_from_raster(mine(opened))
+            assert m1.id == old_id
+            slab.deposit_general(m1, 5, 6.0001, 1.0); got.append(slab.checksum())
+            slab.etch_general(m1, 5, 3, 1.0); got.append(slab.checksum())
+            if got != want:
+                raise AssertionError(f"rank {rank}: {got} != {want}")
+            g.close()
+        except BaseException as e:        # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+            comm.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(parts)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=100)
+    assert not errors, errors[0]
