@@ -1379,15 +1379,16 @@ __device__ __forceinline__ float stream_min_bits(float a, float b) { return __in
 
 // The isotropic etch's update of 4 columns of an output row: A0 = the eroded height from the taps (cg1:704-722), tv = the
 // columns' top records, b4 = the records below them, act = the columns that are open and etchable.
-__device__ __forceinline__ void stream_etch_update(const GridView& g, const StreamOpts& so, const size_t c0, const u32x4 tv, const unsigned act,
-                                                   const uint32_t (&b4)[4], const float (&A0)[4], const int matId, const bool isAll, const double t,
-                                                   const bool m_right, unsigned (&loc)[4]) {
+// (stream_etch_decide works the new tops out into rn[] and returns the columns that changed; stream_etch_update stores them.)
+__device__ __forceinline__ unsigned stream_etch_decide(const GridView& g, const StreamOpts& so, const size_t c0, const u32x4 tv, const unsigned act,
+                                                       const uint32_t (&b4)[4], const float (&A0)[4], const int matId, const bool isAll, const double t,
+                                                       uint32_t (&rn)[4], unsigned (&loc)[4]) {
     // _applyEtchAt (cg1:553-589) by dz = H - Hp (cg1:730-739) on 4 columns.  The usual outcomes -- a cut inside the
     // top layer, or the top layer going as a whole with nothing more to take below -- are decided here, in float
     // arithmetic where that provably gives the reference's numbers and otherwise by the reference's own double
     // expressions; a column that goes on into further layers, rests on a gap, or whose floor lies below the
     // layer under it takes the general form (etch_group4_regs).
-    uint32_t rn[4] = {tv[0], tv[1], tv[2], tv[3]};
+    rn[0] = tv[0]; rn[1] = tv[1]; rn[2] = tv[2]; rn[3] = tv[3];
     double dzs[4] = {0, 0, 0, 0};
     unsigned walk = 0, general = 0, changed = 0;
 #pragma unroll
@@ -1440,6 +1441,14 @@ __device__ __forceinline__ void stream_etch_update(const GridView& g, const Stre
         }
     }
     if (general) changed |= etch_group4_regs<false>(g, c0, general, dzs, matId, isAll, rn, act, b4, loc[2]);
+    return changed;
+}
+
+__device__ __forceinline__ void stream_etch_update(const GridView& g, const StreamOpts& so, const size_t c0, const u32x4 tv, const unsigned act,
+                                                   const uint32_t (&b4)[4], const float (&A0)[4], const int matId, const bool isAll, const double t,
+                                                   const bool m_right, unsigned (&loc)[4]) {
+    uint32_t rn[4];
+    const unsigned changed = stream_etch_decide(g, so, c0, tv, act, b4, A0, matId, isAll, t, rn, loc);
     if (!m_right && (changed || g.top_w != g.top)) {
         u32x4 nv; nv[0] = rn[0]; nv[1] = rn[1]; nv[2] = rn[2]; nv[3] = rn[3];
         st_rec4(g.top_w + c0, nv);
@@ -1510,10 +1519,15 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 // Block = one wave.  Tile = g.ti rows x STRIP columns; tile_of_block names it.
 // quad: the (R+1) x (R+1) quadrant table in device memory (symmetric, since dx == dy).
-template <int R, bool ETCH, bool MSG, bool MASKED>
+// LIC: the host has found every licence of StreamOpts that depends on zscale alone to hold (deq_f32, grow_f32), the usual
+// case; they are then compile-time facts here instead of tests in the row loop (there was a branch in front of every
+// de-quantisation).
+template <int R, bool ETCH, bool MSG, bool MASKED, bool LIC = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_stencil_stream(GridView g, const uint8_t* __restrict__ mask, int matId, double t, int Rimg,
                                                        const uint8_t* __restrict__ halo_lo, const uint8_t* __restrict__ halo_up,
-                                                       const float* __restrict__ quad, const StreamOpts so, int* __restrict__ flags, unsigned long long* gstats) {
+                                                       const float* __restrict__ quad, const StreamOpts so_arg, int* __restrict__ flags, unsigned long long* gstats) {
+    StreamOpts so = so_arg;
+    if (LIC) { so.deq_f32 = 1; so.grow_f32 = 1; }
     using G = StreamGeom<R>;
     constexpr int Rp = G::Rp, PITCH = G::PITCH, W = G::W, TP = STREAM_TAB_PITCH;
     __shared__ __align__(16) float s_row[2][PITCH];

@@ -9,6 +9,7 @@ namespace cgk {
 struct StreamArgs {
     GridView gv; const uint8_t* mask; int mat; double t_eff; int Rimg;
     const uint8_t* halo_lo; const uint8_t* halo_up; const float* d_quad; StreamOpts so; int* flags; unsigned long long* stats;
+    bool lean;      // every licence k_stencil_lean asks for holds (see cg_stencil_lean.hip.h): tiles that read no message take that form
 };
 // k_stencil_stream<Re, etch, msg, masked> on `blocks` one-wave workgroups.  Re = 1..8 (larger: 8).
 void launch_stream(int Re, bool etch, bool msg, bool masked, unsigned blocks, hipStream_t stream, const StreamArgs& a);

@@ -1,5 +1,6 @@
 // k_stencil_stream instantiations for the radii CG_RLO..CG_RHI (one translation unit per pair of radii).
 #include "cg_launch.h"
+#include "cg_stencil_lean.hip.h"
 
 #define CG_CAT2(a, b) a##b
 #define CG_CAT(a, b) CG_CAT2(a, b)
@@ -8,8 +9,18 @@ namespace cgk {
 
 template <int RR>
 static void stream_one(bool etch, bool msg, bool masked, unsigned blocks, hipStream_t s, const StreamArgs& a) {
-#define L(E, M, K) hipLaunchKernelGGL((k_stencil_stream<RR, E, M, K>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.Rimg, \
-                                      a.halo_lo, a.halo_up, a.d_quad, a.so, a.flags, a.stats)
+    if (a.lean && !msg) {
+#define LL(E, K) hipLaunchKernelGGL((k_stencil_lean<RR, E, K>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.d_quad, a.so)
+        if (etch) { if (masked) LL(true, true); else LL(true, false); }
+        else { if (masked) LL(false, true); else LL(false, false); }
+#undef LL
+        return;
+    }
+    const bool lic = a.so.deq_f32 && a.so.grow_f32 && !msg;
+#define L(E, M, K) do { if (lic) hipLaunchKernelGGL((k_stencil_stream<RR, E, M, K, true>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.Rimg, \
+                                      a.halo_lo, a.halo_up, a.d_quad, a.so, a.flags, a.stats); \
+                        else hipLaunchKernelGGL((k_stencil_stream<RR, E, M, K, false>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.Rimg, \
+                                      a.halo_lo, a.halo_up, a.d_quad, a.so, a.flags, a.stats); } while (0)
     if (etch) { if (msg) { if (masked) L(true, true, true); else L(true, true, false); } else { if (masked) L(true, false, true); else L(true, false, false); } }
     else { if (msg) { if (masked) L(false, true, true); else L(false, true, false); } else { if (masked) L(false, false, true); else L(false, false, false); } }
 #undef L
