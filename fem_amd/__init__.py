@@ -5,6 +5,6 @@ is the Python view of that ABI, used by the tests, the benchmark and multi-GPU s
 the JavaScript view (an N-API addon with the reference's ColumnGrid / ProcessRuntime
 surface) lives in fem_amd/js.
 """
-from .colgrid import ColumnGrid, Mask, ColGridError, load_library, reduce_mask  # noqa: F401
+from .colgrid import ColumnGrid, GroupGrid, Mask, ColGridError, load_library, reduce_mask  # noqa: F401
 
-__all__ = ["ColumnGrid", "Mask", "ColGridError", "load_library", "reduce_mask"]
+__all__ = ["ColumnGrid", "GroupGrid", "Mask", "ColGridError", "load_library", "reduce_mask"]

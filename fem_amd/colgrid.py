@@ -58,6 +58,7 @@ ABI = {
     "cg_destroy": (_i, [_vp]),
     "cg_reset": (_i, [_vp, _i]),
     "cg_clear": (_i, [_vp]),
+    "cg_raise_lmax": (_i, [_vp, _i]),
     "cg_get_info": (_i, [_vp, C.POINTER(CgInfo)]),
     "cg_last_error": (C.c_char_p, [_vp]),
     "cg_set_stream": (_i, [_vp, _vp]),
@@ -124,6 +125,46 @@ ABI = {
     "cg_timer_start": (_i, [_vp]),
     "cg_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "cg_version": (C.c_char_p, []),
+    # a grid cut into slabs that the library drives itself (cg_group)
+    "cg_group_create": (_i, [_i, _i, _d, _d, _i, _d, C.POINTER(_i), _i, _pp]),
+    "cg_group_destroy": (_i, [_vp]),
+    "cg_group_last_error": (C.c_char_p, [_vp]),
+    "cg_group_slab_count": (_i, [_vp, C.POINTER(_i)]),
+    "cg_group_slab": (_i, [_vp, _i, _pp]),
+    "cg_group_transport": (_i, [_vp, C.POINTER(_i), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "cg_group_get_info": (_i, [_vp, C.POINTER(CgInfo)]),
+    "cg_group_sync": (_i, [_vp]),
+    "cg_group_reset": (_i, [_vp, _i]),
+    "cg_group_clear": (_i, [_vp]),
+    "cg_group_set_plane_budget": (_i, [_vp, _i]),
+    "cg_group_mask_from_shapes": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(_i)]),
+    "cg_group_mask_from_raster": (_i, [_vp, _vp, _sz, C.POINTER(_i)]),
+    "cg_group_mask_download": (_i, [_vp, _i, _vp, _sz]),
+    "cg_group_mask_destroy": (_i, [_vp, _i]),
+    "cg_group_deposit_general": (_i, [_vp, _i, _i, _d, _d]),
+    "cg_group_etch_general": (_i, [_vp, _i, _i, _d, _d]),
+    "cg_group_cmp": (_i, [_vp, _d, _i]),
+    "cg_group_strip_connected": (_i, [_vp, _i]),
+    "cg_group_identify_cavity": (_i, [_vp]),
+    "cg_group_etch_wet": (_i, [_vp, _i, _d, _d]),
+    "cg_group_etch_wet_step": (_i, [_vp, _i, _i, _i]),
+    "cg_group_deposit_ald": (_i, [_vp, _i, _d, _d]),
+    "cg_group_ald_collect_seeds": (_i, [_vp, _d, C.POINTER(C.c_uint64)]),
+    "cg_group_ald_drop_seeds": (_i, [_vp]),
+    "cg_group_ald_increment": (_i, [_vp, _i, _d]),
+    "cg_group_ald_coat": (_i, [_vp, _i, _d]),
+    "cg_group_release_scratch": (_i, [_vp]),
+    "cg_group_add_layer": (_i, [_vp, _i, _i, _i, _d, _d]),
+    "cg_group_remove_top_layer": (_i, [_vp, _i, _i]),
+    "cg_group_max_height": (_i, [_vp, C.POINTER(_d), C.POINTER(C.c_uint32)]),
+    "cg_group_checksum": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "cg_group_download": (_i, [_vp, _vp, _vp, _vp]),
+    "cg_group_upload": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "cg_group_snapshot_save": (_i, [_vp, _i]),
+    "cg_group_snapshot_load": (_i, [_vp, _i]),
+    "cg_group_snapshot_drop": (_i, [_vp, _i]),
+    "cg_group_slices": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "cg_group_index_from_pos": (_i, [_vp, _i, _d, C.POINTER(C.c_int32)]),
 }
 
 _lib = None
@@ -742,3 +783,160 @@ class ColumnGrid:
         ms = C.c_float()
         self._chk(self.lib.cg_timer_stop(self.h, C.byref(ms)))
         return ms.value
+
+
+class GroupMask:
+    """A mask of a GroupGrid (one device raster per slab behind one id)."""
+
+    def __init__(self, grid, mask_id):
+        self.grid, self.id = grid, mask_id
+
+    def download(self):
+        out = np.empty(self.grid.NX * self.grid.NY, np.uint8)
+        self.grid._chk(self.grid.lib.cg_group_mask_download(self.grid.h, self.id, out.ctypes.data, out.size))
+        return out
+
+    def destroy(self):
+        if self.id is not None and self.grid.h:
+            self.grid.lib.cg_group_mask_destroy(self.grid.h, self.id)
+        self.id = None
+
+
+class GroupGrid:
+    """One grid cut into slabs that the LIBRARY drives (cg_group_*, include/colgrid.h): the reference's ColumnGrid call
+    surface over several devices from one process.  devices: one HIP device ordinal per slab (repeats allowed)."""
+
+    def __init__(self, LXnm, LYnm, dx=2.0, dy=2.0, LmaxInit=32, zScale=0.1, *, devices=(0,), lib=None):
+        self.lib = lib or load_library()
+        self.h = None
+        nx = max(1, int(ColumnGrid._js_round(LXnm / dx)))                 # setDomain (script_columngrid.js:49-60)
+        ny = max(1, int(ColumnGrid._js_round(LYnm / dy)))
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        out = C.c_void_p()
+        rc = self.lib.cg_group_create(nx, ny, dx, dy, LmaxInit, zScale, devs, len(devices), C.byref(out))
+        if rc:
+            raise ColGridError(rc, (self.lib.cg_group_last_error(None) or b"").decode())
+        self.h = out
+        self.zScale = zScale
+
+    def _chk(self, rc):
+        if rc:
+            raise ColGridError(rc, (self.lib.cg_group_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if self.h:
+            self.lib.cg_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        inf = CgInfo()
+        self._chk(self.lib.cg_group_get_info(self.h, C.byref(inf)))
+        return inf
+
+    NX = property(lambda s: s.info().nx)
+    NY = property(lambda s: s.info().ny)
+    Lmax = property(lambda s: s.info().lmax)
+
+    def transport(self):
+        """-> (uses RCCL, exchanges so far, bytes moved so far)."""
+        r, e, b = C.c_int(), C.c_uint64(), C.c_uint64()
+        self._chk(self.lib.cg_group_transport(self.h, C.byref(r), C.byref(e), C.byref(b)))
+        return bool(r.value), e.value, b.value
+
+    def sync(self):
+        self._chk(self.lib.cg_group_sync(self.h))
+
+    # ---- masks
+    def mask_from_raster(self, raster):
+        r = np.ascontiguousarray(raster, dtype=np.uint8).reshape(-1)
+        mid = C.c_int()
+        self._chk(self.lib.cg_group_mask_from_raster(self.h, r.ctypes.data, r.size, C.byref(mid)))
+        return GroupMask(self, mid.value)
+
+    def mask_from_shapes(self, reduced):
+        arr, n, pts = _pack_shapes(reduced)
+        mid = C.c_int()
+        self._chk(self.lib.cg_group_mask_from_shapes(self.h, arr.ctypes.data if n else None, n,
+                                                     pts.ctypes.data if pts.size else None, pts.size // 2, C.byref(mid)))
+        return GroupMask(self, mid.value)
+
+    @staticmethod
+    def _mid(mask):
+        if mask is None:
+            return CG_MASK_NONE
+        if isinstance(mask, GroupMask):
+            return mask.id
+        raise TypeError("mask must be None or a GroupMask made by this grid")
+
+    # ---- the reference's step methods
+    def deposit_general(self, mask, matId, thickness, conformality=1.0):
+        self._chk(self.lib.cg_group_deposit_general(self.h, self._mid(mask), int(matId), float(thickness), float(conformality)))
+
+    def etch_general(self, mask, matId, thickness, conformality=1.0):
+        self._chk(self.lib.cg_group_etch_general(self.h, self._mid(mask), int(matId), float(thickness), float(conformality)))
+
+    def cmp(self, depth, stopMatId=0):
+        self._chk(self.lib.cg_group_cmp(self.h, float(depth), int(stopMatId)))
+
+    def strip_connected(self, matId):
+        self._chk(self.lib.cg_group_strip_connected(self.h, int(matId)))
+
+    def identify_cavity(self):
+        self._chk(self.lib.cg_group_identify_cavity(self.h))
+
+    def etch_wet(self, matId, totalThk, dt=None):
+        self._chk(self.lib.cg_group_etch_wet(self.h, int(matId), float(totalThk), float("nan") if dt is None else float(dt)))
+
+    def deposit_ALD(self, matId, totalThk, dt=None):
+        self._chk(self.lib.cg_group_deposit_ald(self.h, int(matId), float(totalThk), float("nan") if dt is None else float(dt)))
+
+    def createNewGrid(self, LmaxInit=0):
+        self._chk(self.lib.cg_group_reset(self.h, int(LmaxInit)))
+
+    def maxHeight(self):
+        z = C.c_double()
+        self._chk(self.lib.cg_group_max_height(self.h, C.byref(z), None))
+        return z.value
+
+    def checksum(self):
+        s = C.c_uint64()
+        self._chk(self.lib.cg_group_checksum(self.h, C.byref(s)))
+        return s.value
+
+    def download(self):
+        """-> (len, mat, zpair) of the whole grid in the reference layout."""
+        inf = self.info()
+        n, L = inf.nx * inf.ny, inf.lmax
+        ln = np.empty(n, np.uint8); mat = np.empty(n * L, np.uint8); zp = np.empty(2 * n * L, np.uint16)
+        self._chk(self.lib.cg_group_download(self.h, mat.ctypes.data, zp.ctypes.data, ln.ctypes.data))
+        return ln, mat, zp
+
+    def upload(self, ln, mat, zp, lmax):
+        ln = np.ascontiguousarray(ln, np.uint8); mat = np.ascontiguousarray(mat, np.uint8); zp = np.ascontiguousarray(zp, np.uint16)
+        self._chk(self.lib.cg_group_upload(self.h, mat.ctypes.data, zp.ctypes.data, ln.ctypes.data, int(lmax)))
+
+    def snapshot_save(self, slot):
+        self._chk(self.lib.cg_group_snapshot_save(self.h, int(slot)))
+
+    def snapshot_load(self, slot):
+        self._chk(self.lib.cg_group_snapshot_load(self.h, int(slot)))
+
+    def snapshot_drop(self, slot):
+        self._chk(self.lib.cg_group_snapshot_drop(self.h, int(slot)))
+
+    def slices(self, axis, indices):
+        ax = {"YZ": 0, "XZ": 1}[axis] if isinstance(axis, str) else int(axis)
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        inf = self.info()
+        line = inf.ny if ax == 0 else inf.nx
+        L, cnt = inf.lmax, idx.size
+        ln = np.empty(cnt * line, np.uint8); mat = np.empty(cnt * line * L, np.uint8)
+        zp = np.empty(2 * cnt * line * L, np.uint16)
+        self._chk(self.lib.cg_group_slices(self.h, ax, idx.ctypes.data, cnt, mat.ctypes.data, zp.ctypes.data, ln.ctypes.data))
+        return ln.reshape(cnt, line), mat.reshape(cnt, line, L), zp.reshape(cnt, line, L, 2)

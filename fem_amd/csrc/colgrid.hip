@@ -1199,6 +1199,13 @@ int cg_set_plane_budget(cg_grid* g, int max_planes) {
     return CG_OK;
 }
 
+int cg_raise_lmax(cg_grid* g, int lmax) {
+    NEED_H0(g);
+    if (lmax < 1 || lmax > 256) return fail(g, CG_ERR_ARG, "Lmax %d outside 1..256", lmax);
+    if (lmax > g->lmax_vis) g->lmax_vis = lmax;
+    return CG_OK;
+}
+
 int cg_clear(cg_grid* g) { NEED_H0(g); g->vq.clear(); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
 
 int cg_get_info(const cg_grid* g, cg_info* o) {

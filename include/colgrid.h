@@ -120,6 +120,12 @@ int cg_reset(cg_grid* g, int lmax_init);
  * No counterpart in the reference; the Lmax a caller sees (cg_info.lmax) does not depend on it. */
 int cg_set_plane_budget(cg_grid* g, int max_planes);
 
+/* The reference's Lmax belongs to the whole grid: += 16 whenever an append finds its column full, wherever that
+ * column is (cg1:129-168, 418).  Every slab of a decomposed domain follows that rule for its own columns; the
+ * driver raises all of them to the largest after a step (never lowers: a smaller value is ignored).  No counterpart
+ * in the reference (one array, one Lmax). */
+int cg_raise_lmax(cg_grid* g, int lmax);
+
 /* clearAll() (cg1:223-227): empty every column, keep Lmax. */
 int cg_clear(cg_grid* g);
 
@@ -375,6 +381,62 @@ int cg_slices_noalloc(cg_grid* g, int axis, const int32_t* index, int count,
 
 /* indexFromX / indexFromY (sl:15-16): clamp(round((pos - offset)/pitch), 0, n-1). */
 int cg_index_from_pos(const cg_grid* g, int axis, double pos_nm, int32_t* index);
+
+/* ---- a grid cut into slabs that the library drives itself --------------------------------------------
+ * No counterpart in the reference (it is single-threaded, one array).  A cg_group is ONE grid of nx_global x ny
+ * columns whose rows are dealt out over `nslabs` slab handles, slab k on HIP device devices[k] (several slabs may
+ * name the same device); the calling process drives all of them.  Every cg_group_* call below is the handle call of
+ * the same name applied to the whole domain -- same arguments, same results as on an undivided grid, bit for bit:
+ * lateral steps swap R halo rows between neighbouring slabs (the rows that need none are updated while those
+ * travel), strip_connected / identify_cavity flood across the slab edges, cmp / maxHeight / etch_wet / deposit_ALD
+ * combine the slabs' scalars, cg_group_download / _upload / _slices use the reference layout of the WHOLE grid, and
+ * cg_info.lmax is the reference's one Lmax.  Rows travel device to device over RCCL (ncclSend / ncclRecv) when every
+ * slab has a device of its own and librccl can be loaded, by hipMemcpyPeerAsync otherwise; the environment variable
+ * CG_GROUP_TRANSPORT=copy|rccl forces one.  Mask ids are the group's own.  A group is not re-entrant.
+ * This is the one-process form of the decomposition; fem_amd/slabs.py drives the same handle calls with one process
+ * per GPU over torch.distributed. */
+typedef struct cg_group cg_group;
+int cg_group_create(int nx_global, int ny, double dx, double dy, int lmax_init, double zscale,
+                    const int* devices, int nslabs, cg_group** out);
+int cg_group_destroy(cg_group* g);
+const char* cg_group_last_error(const cg_group* g);           /* g == NULL: the last failed create on this thread */
+int cg_group_slab_count(const cg_group* g, int* nslabs);
+int cg_group_slab(cg_group* g, int k, cg_grid** slab);        /* the handle of slab k (owned by the group) */
+/* which transport the group uses (1 = RCCL), and how many exchanges / bytes it has moved so far */
+int cg_group_transport(const cg_group* g, int* rccl, uint64_t* exchanges, uint64_t* bytes_moved);
+int cg_group_get_info(cg_group* g, cg_info* out);             /* nx = nx_global, i0 = 0, lmax = the domain's */
+int cg_group_sync(cg_group* g);
+int cg_group_reset(cg_group* g, int lmax_init);                                                   /* cg_reset */
+int cg_group_clear(cg_group* g);                                                                  /* cg_clear */
+int cg_group_set_plane_budget(cg_group* g, int max_planes);
+int cg_group_mask_from_shapes(cg_group* g, const cg_shape* shapes, int nshapes, const double* pts, int npts, int* mask_id);
+int cg_group_mask_from_raster(cg_group* g, const uint8_t* host_raster, size_t n, int* mask_id);  /* n = nx_global*ny */
+int cg_group_mask_download(cg_group* g, int mask_id, uint8_t* host_out, size_t n);
+int cg_group_mask_destroy(cg_group* g, int mask_id);
+int cg_group_deposit_general(cg_group* g, int mask_id, int mat, double thickness, double conformality);   /* cg1:435-544 */
+int cg_group_etch_general(cg_group* g, int mask_id, int mat, double thickness, double conformality);      /* cg1:598-740 */
+int cg_group_cmp(cg_group* g, double depth, int stop_mat);                                               /* cg1:747-859 */
+int cg_group_strip_connected(cg_group* g, int mat);                                                      /* cg1:867 - cg2:1 */
+int cg_group_identify_cavity(cg_group* g);                                                               /* cg2:9-83 */
+int cg_group_etch_wet(cg_group* g, int mat, double total_thickness, double dt);                           /* cg_etch_wet */
+int cg_group_etch_wet_step(cg_group* g, int mat, int dt_q, int use_diagonal);                             /* cg_etch_wet_step */
+int cg_group_deposit_ald(cg_group* g, int mat, double total_thickness, double dt);                        /* cg_deposit_ald */
+int cg_group_ald_collect_seeds(cg_group* g, double total_thickness, uint64_t* count);                     /* cg_ald_collect_seeds */
+int cg_group_ald_drop_seeds(cg_group* g);
+int cg_group_ald_increment(cg_group* g, int mat, double t);                                               /* cg_ald_increment */
+int cg_group_ald_coat(cg_group* g, int mat, double t);                                                    /* cg_ald_coat */
+int cg_group_release_scratch(cg_group* g);
+int cg_group_add_layer(cg_group* g, int i, int j, int mat, double z0_nm, double z1_nm);                   /* global i */
+int cg_group_remove_top_layer(cg_group* g, int i, int j);
+int cg_group_max_height(cg_group* g, double* z_nm, uint32_t* top_q);                                      /* cg2:85-104 */
+int cg_group_checksum(cg_group* g, uint64_t* sum);
+int cg_group_download(cg_group* g, uint8_t* mat, uint16_t* zpair, uint8_t* len);
+int cg_group_upload(cg_group* g, const uint8_t* mat, const uint16_t* zpair, const uint8_t* len, int lmax);
+int cg_group_snapshot_save(cg_group* g, int slot);
+int cg_group_snapshot_load(cg_group* g, int slot);
+int cg_group_snapshot_drop(cg_group* g, int slot);
+int cg_group_slices(cg_group* g, int axis, const int32_t* index, int count, uint8_t* mat, uint16_t* zpair, uint8_t* len);
+int cg_group_index_from_pos(const cg_group* g, int axis, double pos_nm, int32_t* index);
 
 /* ---- checks and measurement ---------------------------------------------------------- */
 

@@ -1138,3 +1138,71 @@ def test_slab_driver_when_a_mask_id_is_handed_out_again():
     for t in threads:
         t.join(timeout=100)
     assert not errors, errors[0]
+
+
+@pytest.mark.parametrize("parts,flow_name", [(2, "c4"), (3, "c4"), (2, "cs"), (3, "cs"), (2, "cwet"), (3, "cw"), (1, "cs")])
+def test_group_driven_by_the_library(parts, flow_name):
+    """cg_group_*: the slab decomposition driven below the C ABI (one process, `parts` slabs on one device, rows moved
+    by device copies on per-slab transfer streams): the same checksum, maximum height and Lmax as the oracle after
+    every step, and the whole grid's arrays at the end."""
+    fem = _engine()
+    from fem_amd import flows
+    nx, ny = 40 * parts + (1 if parts == 3 else 0), 72           # 121 rows over 3 slabs: uneven slabs
+    flow = flows.FLOWS[flow_name]()
+    specs = flows.mask_specs(2.0 * nx)
+    g = fem.GroupGrid(2.0 * nx, 2.0 * ny, 2.0, 2.0, devices=[0] * parts)
+    o = OracleGrid(2.0 * nx, 2.0 * ny, 2.0, 2.0)
+    gm, om = {}, {}
+    for name in sorted({s["mask"] for s in flow if s["mask"]}):
+        red = fem.reduce_mask(flows.shapes_of(specs[name], 2 * nx, 2 * ny))
+        gm[name] = g.mask_from_shapes(red)
+        om[name] = o.mask_raster(red)
+        np.testing.assert_array_equal(gm[name].download(), om[name])
+    for k, st in enumerate(flow):
+        flows.apply_step(g, st, gm)
+        flows.apply_step(o, st, om)
+        o.slider_reset()
+        assert g.checksum() == o.checksum(), f"step {k} {st}"
+        assert g.maxHeight() == o.max_height() and g.Lmax == o.Lmax, f"step {k} {st}"
+    ln, mat, zp = g.download()
+    oln, omat, ozp = o.arrays()
+    np.testing.assert_array_equal(ln, oln); np.testing.assert_array_equal(mat, omat); np.testing.assert_array_equal(zp, ozp)
+    # cross-sections of the whole domain, both ways, against the downloaded arrays
+    L = g.Lmax
+    idx = [0, nx // 2, nx - 1]
+    sl, sm, sz = g.slices("YZ", idx)
+    for q, i in enumerate(idx):
+        np.testing.assert_array_equal(sl[q], ln.reshape(nx, ny)[i]); np.testing.assert_array_equal(sm[q], mat.reshape(nx, ny, L)[i])
+    jdx = [1, ny - 2]
+    sl, sm, sz = g.slices("XZ", jdx)
+    for q, j in enumerate(jdx):
+        np.testing.assert_array_equal(sl[q], ln.reshape(nx, ny)[:, j]); np.testing.assert_array_equal(sz[q], zp.reshape(nx, ny, L, 2)[:, j])
+    if parts > 1:
+        rccl, exchanges, moved = g.transport()
+        assert not rccl and exchanges > 0 and moved > 0            # slabs sharing a device: device copies
+    g.close()
+
+
+def test_group_when_a_mask_id_is_handed_out_again():
+    """The group's own 'does this mask open a cell anywhere' answer dies with the mask: the id of a destroyed all-closed
+    mask goes to an open one, and the lateral deposit through it must happen -- with the kernel the skipped step left in
+    the kernel cache (thicknesses closer than 1e-3 share a cache key, script_columngrid.js:326, 470)."""
+    fem = _engine()
+    nx, ny = 48, 40
+    g = fem.GroupGrid(2.0 * nx, 2.0 * ny, 2.0, 2.0, devices=[0, 0])
+    o = OracleGrid(2.0 * nx, 2.0 * ny, 2.0, 2.0)
+    closed = np.zeros(nx * ny, np.uint8)
+    opened = (np.random.RandomState(11).rand(nx * ny) < 0.7).astype(np.uint8)
+    g.deposit_general(None, 3, 20, 0); o.deposit_general(None, 3, 20, 0)
+    m0 = g.mask_from_raster(closed)
+    g.deposit_general(m0, 4, 6.0004, 1.0); o.deposit_general(closed, 4, 6.0004, 1.0)
+    assert g.checksum() == o.checksum()
+    old = m0.id
+    m0.destroy()
+    m1 = g.mask_from_raster(opened)
+    assert m1.id == old
+    g.deposit_general(m1, 5, 6.0001, 1.0); o.deposit_general(opened, 5, 6.0001, 1.0)
+    assert g.checksum() == o.checksum()
+    g.etch_general(m1, 5, 3, 1.0); o.etch_general(opened, 5, 3, 1.0)
+    assert g.checksum() == o.checksum()
+    g.close()
