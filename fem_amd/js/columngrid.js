@@ -34,13 +34,19 @@ function maskFunctionFor(maskData, jsPredicate) {
 }
 
 class ColumnGrid {
-  constructor(LXnm, LYNm, dx, dy, LmaxInit = 32, zScale = 0.1) {
+  // opts.devices (no counterpart in the reference): HIP device ordinals, one per slab.  The grid is then cut into that
+  // many slabs of rows, slab k on device devices[k] (repeats allowed), and the library drives them as one grid
+  // (cg_group_*, include/colgrid.h): every method below behaves as on one device, results included.
+  constructor(LXnm, LYNm, dx, dy, LmaxInit = 32, zScale = 0.1, opts = {}) {
     this.zScale = zScale;
     this.expandStep = 16;
     this.nMaxCache = 10;
-    this._h = addon.create(Number(LXnm), Number(LYNm), Number(dx), Number(dy), LmaxInit, zScale);
+    const devices = opts && opts.devices;
+    this._h = (devices && devices.length > 0)
+      ? addon.createGroup(Number(LXnm), Number(LYNm), Number(dx), Number(dy), LmaxInit, zScale, Int32Array.from(devices))
+      : addon.create(Number(LXnm), Number(LYNm), Number(dx), Number(dy), LmaxInit, zScale);
     this._cols = null;
-    this._maskIds = new Map();          // reduced-shape JSON -> device mask id
+    this._maskIds = new Map();          // reduced shape list (the object a mask closure carries) -> device mask id
     this._nextSlot = 0;
     this.colsCache = {};
     this._sliderCache = {};
@@ -99,12 +105,13 @@ class ColumnGrid {
     const reduced = maskFn[SHAPES];
     if (reduced) {
       if (reduced.open) return MASK_NONE;
-      const key = JSON.stringify(reduced);
-      let id = this._maskIds.get(key);
+      // keyed by the identity of the reduced list: a closure that is handed in again (the runtime keeps one per mask
+      // record) costs a map lookup, not a walk over its shapes
+      let id = this._maskIds.get(reduced);
       if (id === undefined) {
         const p = packShapes(reduced);
         id = addon.maskFromShapes(this._h, p.shapes, p.nshapes, p.pts);
-        this._maskIds.set(key, id);
+        this._maskIds.set(reduced, id);
         if (this._maskIds.size > 64) {                               // bound the device rasters we keep
           const [k0, id0] = this._maskIds.entries().next().value;
           addon.maskDestroy(this._h, id0); this._maskIds.delete(k0);
@@ -283,6 +290,8 @@ class ColumnGrid {
   slices(axis, indices) { return addon.slices(this._h, axis === 'XZ' ? 1 : 0, Int32Array.from(indices)); }
 
   checksum() { return addon.checksum(this._h); }
+  // { rccl, exchanges, bytes }: how rows have crossed slab edges so far (all zero on one device)
+  transport() { return addon.groupTransport(this._h); }
 }
 
 module.exports = { ColumnGrid, maskFunctionFor, addon };

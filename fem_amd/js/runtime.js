@@ -74,9 +74,10 @@ class ProcessRuntime {
     this.domain = env.domain || { LX: 200, LY: 200, dx: 2, dy: 2 };           // script_runtime.js:15
     const Grid = env.ColumnGrid || ColumnGrid;
     const { LX, LY, dx, dy } = this.domain;
-    this.grid = new Grid(LX, LY, dx, dy);
+    // env.devices (no counterpart in the reference): the HIP devices to cut the grid over, one slab each
+    this.grid = env.devices ? new Grid(LX, LY, dx, dy, 32, 0.1, { devices: env.devices }) : new Grid(LX, LY, dx, dy);
     this.oldUpto = null;
-    this._maskFns = new Map();
+    this._maskFns = new Map();         // mask id -> { data, fn }: the closure made for that mask record's data
   }
 
   _materialColor() { return this.env.processFlow ? this.env.processFlow.materialColor : (this.env.materialColor || {}); }
@@ -90,11 +91,19 @@ class ProcessRuntime {
 
   // script_runtime.js:45-52.  The closure answers like the reference's and also carries the
   // reduced shapes, so the GPU grid rasterises it itself instead of calling it per cell.
+  // One closure per mask record is kept for as long as the record holds the same `data` object: the mask editor
+  // replaces `data` by a fresh canvas.toJSON() whenever a mask is saved (template/script_maskeditor.js:206, 240-245),
+  // so identity of `data` is the record's version.  A flow of many steps through one mask then reduces its shapes
+  // once, and the grid (which keys its device rasters by the reduced list) rasterises it once.
   _getMaskFun(maskid) {
     if (!maskid || maskid == '-') return () => true;
     const rec = this._maskList().find(m => m.id === maskid);
     const data = rec.data;                                    // a missing record throws, as in the reference
-    return maskFunctionFor(data, (x, y) => isPointOpen(x, y, data));
+    const kept = this._maskFns.get(maskid);
+    if (kept && kept.data === data) return kept.fn;
+    const fn = maskFunctionFor(data, (x, y) => isPointOpen(x, y, data));
+    this._maskFns.set(maskid, { data, fn });
+    return fn;
   }
 
   _applyStep(grid, step, useProcCache = false) {              // script_runtime.js:143-181

@@ -87,4 +87,82 @@ for (const nx of [64, 256]) {
   same(s.mat, cols.mat.subarray(i * NY * L, (i + 1) * NY * L), 'slice mat');
   rt.grid.dispose();
 }
+
+// ---- one grid over several slabs, driven by the library (cg_group_*): configuration C4's 20 steps through the JavaScript
+// class with 2 and 3 slabs on one device must leave the same grid as the undivided one after every step
+{
+  const NXc = 122, NYc = 72, L = 2 * NXc;
+  const obj = (type, left, top, w, h, polarity, extra) => Object.assign({ type, left, top, width: w, height: h, angle: 0, scaleX: 1, scaleY: 1,
+    visible: true, data: { polarity } }, extra || {});
+  const periodic = (pitch, size, shift, circle) => {
+    const objects = [];
+    for (let x = shift; x < 2 * NXc; x += pitch) for (let y = shift; y < 2 * NYc; y += pitch)
+      objects.push(circle ? obj('circle', x, y, 2 * size, 2 * size, 'positive', { radius: size }) : obj('rect', x, y, size, size, 'positive'));
+    return { objects };
+  };
+  const masks = {
+    M: periodic(64, 32, 0, false), Mshift: periodic(64, 32, 16, false), Mc: periodic(48, 12, 0, true),
+    Mr: { objects: [obj('rect', 0, 0, 4 * L, 4 * L, 'positive'), obj('rect', 0.30 * L, 0.05 * L, 0.55 * L, 0.35 * L, 'negative', { angle: 30 })] },
+  };
+  const SI = 3, OX = 4, NIT = 5, M6 = 6, M7 = 7, ALL = 255;
+  const D = (mask, mat, t, S) => ({ op: 'd', mask, mat, t, S: S || 0 }), E = (mask, mat, t, S) => ({ op: 'e', mask, mat, t, S: S || 0 });
+  const flow = [D(null, SI, 30), D(null, OX, 20), D(null, NIT, 10), E('M', NIT, 10), E('M', OX, 12), D(null, NIT, 10, 1.0), E(null, NIT, 6, 1.0),
+    D(null, M6, 8, 0.5), E('Mc', M6, 8), D(null, M7, 15), E('Mshift', ALL, 10), E('Mshift', SI, 5), D(null, OX, 12, 1.0), E('Mr', OX, 4, 1.0),
+    D(null, NIT, 6, 0.5), E('Mc', NIT, 6), D(null, M6, 30), E('M', M6, 30, 0.5), D(null, M7, 4, 1.0), E('Mr', ALL, 8),
+    { op: 'cmp', t: 6, mat: 0 }, { op: 'strip', mat: OX }, D(null, OX, 5, 1.0), { op: 'wet', mat: M7, t: 3 }, { op: 'ald', mat: NIT, t: 4 }];
+  const apply = (g, fns, s) => {
+    const fn = s.mask ? fns[s.mask] : null;
+    if (s.op === 'd') g.deposit_general(fn, s.mat, s.t, s.S);
+    else if (s.op === 'e') g.etch_general(fn, s.mat, s.t, s.S);
+    else if (s.op === 'cmp') g.cmp(s.t, s.mat);
+    else if (s.op === 'strip') g.strip_connected(s.mat);
+    else if (s.op === 'wet') g.etch_wet(s.mat, s.t);
+    else g.deposit_ALD(s.mat, s.t);
+  };
+  const whole = new ColumnGrid(2 * NXc, 2 * NYc, 2, 2);
+  const wfns = {}; for (const k of Object.keys(masks)) wfns[k] = maskFunctionFor(masks[k]);
+  const want = flow.map(s => { apply(whole, wfns, s); return [whole.checksum(), whole.maxHeight(), whole.Lmax]; });
+  whole.saveCache('final');
+  for (const devices of [[0, 0], [0, 0, 0]]) {
+    const g = new ColumnGrid(2 * NXc, 2 * NYc, 2, 2, 32, 0.1, { devices });
+    assert.strictEqual(g.NX, NXc); assert.strictEqual(g.NY, NYc);
+    const fns = {}; for (const k of Object.keys(masks)) fns[k] = maskFunctionFor(masks[k]);
+    flow.forEach((s, idx) => { apply(g, fns, s); assert.deepStrictEqual([g.checksum(), g.maxHeight(), g.Lmax], want[idx], `${devices.length} slabs, step ${idx} ${JSON.stringify(s)}`); });
+    const a = g.cols, b = whole.cols;
+    same(a.len, b.len, 'group len'); same(a.mat, b.mat, 'group mat'); same(a.zpair, b.zpair, 'group zpair');
+    const tr = g.transport();
+    assert.ok(tr.exchanges > 0 && tr.bytes > 0 && tr.rccl === false, 'rows crossed the slab edges by device copies');
+    // a plain closure (evaluated per cell on the host, uploaded as one raster of the whole grid) across the slabs
+    g.etch_general((x, y) => x + y > 150, ALL, 3, 1.0); whole.etch_general((x, y) => x + y > 150, ALL, 3, 1.0);
+    assert.strictEqual(g.checksum(), whole.checksum(), 'host-evaluated mask over slabs');
+    whole.loadCache('final');
+    g.dispose();
+  }
+  whole.dispose();
+}
+
+// ---- the flow driver walks a mask's objects once, however many steps go through the mask
+{
+  const { reduceMask } = require(path.join(ROOT, 'fem_amd', 'js', 'maskshapes.js'));
+  const objects = [];
+  for (let a = 0; a < 128; a++) for (let b = 0; b < 128; b++)
+    objects.push({ type: 'rect', left: 4 * a, top: 4 * b, width: 2, height: 2, angle: 0, scaleX: 1, scaleY: 1, visible: true, data: { polarity: 'positive' } });
+  assert.strictEqual(objects.length, 16384);
+  const maskList = [{ id: 'mask0000000001', name: 'dots', data: { objects } }];
+  const materialColor = { Si: { color: '#888', id: 3 }, Ox: { color: '#00f', id: 4 } };
+  const processes = [{ id: 'p0', kind: 'SUBSTR', mask: '-', material: 'Si', thickness: 20, name: 's' }];
+  for (let k = 1; k < 20; k++)
+    processes.push({ id: 'p' + k, kind: k % 2 ? 'ETCH' : 'DEPO', mask: 'mask0000000001', material: k % 2 ? 'ALL' : 'Ox', thickness: 2 + k % 3, conformality: 0, name: 'x' + k });
+  const rt = new ProcessRuntime({ domain: { LX: 512, LY: 512, dx: 2, dy: 2 }, processFlow: { materialColor }, maskmanager: { maskList } });
+  const before = reduceMask.calls;
+  rt.onSimflowChanged({ processes, arrowBoundId: 'p19', materialColor, opts: { typ: 'process', procId: 'p19' } });
+  assert.strictEqual(reduceMask.calls - before, 1, '20 steps through one 16 384-shape mask reduce it once');
+  assert.strictEqual(rt.grid._maskIds.size, 1, 'and rasterise it once');
+  // the editor saves the mask: a new data object, hence a new closure and a new raster
+  maskList[0].data = { objects: objects.slice(0, 100) };
+  rt.oldUpto = null;
+  rt.onSimflowChanged({ processes, arrowBoundId: 'p19', materialColor, opts: { typ: 'maskchange', procId: 'p1' } });
+  assert.strictEqual(reduceMask.calls - before, 2, 'a saved mask is reduced again, once');
+  rt.grid.dispose();
+}
 console.log('js gpu tests ok');
