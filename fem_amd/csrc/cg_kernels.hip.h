@@ -1814,31 +1814,8 @@ static __global__ __launch_bounds__(256) void k_mask_shapes(int nx, int ny, int 
     }
 }
 
-// The same predicate with the shapes binned by the host: a tile of MASK_TILE x MASK_TILE cells walks
-// only the shapes whose bounding box reaches it (tile_list[tile_off[t] .. tile_off[t+1]), ascending
-// shape index) merged with the few shapes that reach a large part of the grid (wide, ascending),
-// from the last shape to the first as the reference does (rt:58).
+// tiles of the binned rasteriser (cg_mask_bin.hip.h)
 constexpr int MASK_TILE = 32;
-
-static __global__ __launch_bounds__(256) void k_mask_shapes_binned(int nx, int ny, int i0, double dx, double dy, const Shape* __restrict__ shapes,
-                                                            const double* __restrict__ pts, int tiles_j, const int* __restrict__ tile_off,
-                                                            const int* __restrict__ tile_list, const int* __restrict__ wide, int nwide,
-                                                            uint8_t* __restrict__ raster) {
-    const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
-    const int b = tile_off[blockIdx.x], e = tile_off[blockIdx.x + 1];
-    for (int k = threadIdx.x; k < MASK_TILE * MASK_TILE; k += blockDim.x) {
-        const int i = ti * MASK_TILE + k / MASK_TILE, j = tj * MASK_TILE + k % MASK_TILE;
-        if (i >= nx || j >= ny) continue;
-        const double x = ((double)(i0 + i) + 0.5) * dx, y = ((double)j + 0.5) * dy;
-        int open = 1, a = e - 1, w = nwide - 1;
-        while (a >= b || w >= 0) {
-            int s;
-            if (w < 0 || (a >= b && tile_list[a] > wide[w])) s = tile_list[a--]; else s = wide[w--];
-            if (point_inside_shape(x, y, shapes[s], pts)) { open = !shapes[s].positive; break; }
-        }
-        raster[(size_t)i * ny + j] = (uint8_t)open;
-    }
-}
 
 // out[0] = 1 if any byte of the raster is non-zero (n bytes; 4 at a time, then the tail)
 static __global__ __launch_bounds__(256) void k_mask_any(const uint8_t* __restrict__ m, size_t n, unsigned* __restrict__ out) {

@@ -18,6 +18,7 @@
 #include "../../include/colgrid.h"
 #include "cg_kernels.hip.h"
 #include "cg_interval_kernels.hip.h"
+#include "cg_mask_bin.hip.h"
 #include "cg_launch.h"
 
 using namespace cgk;
@@ -1288,89 +1289,6 @@ int cg_mask_from_device_raster(cg_grid* g, const void* dev, size_t n, int* mask_
     return CG_OK;
 }
 
-namespace {
-// World-space box [x0, x1] x [y0, y1] outside which shape s contains no point (rt:73-129), or false when no
-// finite box can be vouched for.  Empty shapes get an empty box (x1 < x0).
-bool shape_box(const cg_shape& s, const double* pts, double* x0, double* x1, double* y0, double* y1) {
-    double lx0, lx1, ly0, ly1;                                   // the box in the shape's own frame
-    switch (s.type) {
-    case CG_SHAPE_RECT: lx0 = std::min(0.0, s.w); lx1 = std::max(0.0, s.w); ly0 = std::min(0.0, s.h); ly1 = std::max(0.0, s.h); break;
-    case CG_SHAPE_CIRCLE: lx0 = s.w / 2 - std::fabs(s.a); lx1 = s.w / 2 + std::fabs(s.a); ly0 = s.h / 2 - std::fabs(s.a); ly1 = s.h / 2 + std::fabs(s.a); break;
-    case CG_SHAPE_ELLIPSE: lx0 = s.w / 2 - std::fabs(s.a); lx1 = s.w / 2 + std::fabs(s.a); ly0 = s.h / 2 - std::fabs(s.b); ly1 = s.h / 2 + std::fabs(s.b); break;
-    case CG_SHAPE_POLYGON: {
-        if (s.pt_cnt <= 0) { *x0 = *y0 = 1; *x1 = *y1 = 0; return true; }
-        const double* p = pts + 2 * (size_t)s.pt_off;
-        lx0 = lx1 = p[0]; ly0 = ly1 = p[1];
-        for (int k = 0, j = s.pt_cnt - 1; k < s.pt_cnt; j = k++) {
-            lx0 = std::min(lx0, p[2 * k]); lx1 = std::max(lx1, p[2 * k]); ly0 = std::min(ly0, p[2 * k + 1]); ly1 = std::max(ly1, p[2 * k + 1]);
-            // the crossing test divides by (yj - yi + 1e-9) (rt:137): on an edge flatter than that guard a
-            // crossing can land anywhere, so no box is vouched for
-            const double ey = p[2 * j + 1] - p[2 * k + 1];
-            if (ey != 0 && std::fabs(ey) < 1e-6) return false;
-        }
-        break;
-    }
-    default: *x0 = *y0 = 1; *x1 = *y1 = 0; return true;          // never contains a point (rt:126)
-    }
-    double c = 1, sn = 0;
-    if (s.rotated) { c = s.cosr; sn = s.sinr; }
-    const double det = c * c + sn * sn;
-    if (!(det > 1e-12) || !std::isfinite(det)) return false;
-    double bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
-    for (int k = 0; k < 4; k++) {
-        const double u = ((k & 1) ? lx1 : lx0) * s.scale_x, v = ((k & 2) ? ly1 : ly0) * s.scale_y;      // undo lx /= scaleX (rt:92)
-        const double wx = s.left + (c * u + sn * v) / det, wy = s.top + (-sn * u + c * v) / det;       // undo the rotation (rt:88-90)
-        bx0 = std::min(bx0, wx); bx1 = std::max(bx1, wx); by0 = std::min(by0, wy); by1 = std::max(by1, wy);
-    }
-    if (!std::isfinite(bx0) || !std::isfinite(bx1) || !std::isfinite(by0) || !std::isfinite(by1)) return false;
-    const double pad = 1e-6 + 1e-9 * std::max(std::max(std::fabs(bx0), std::fabs(bx1)), std::max(std::fabs(by0), std::fabs(by1)));
-    *x0 = bx0 - pad; *x1 = bx1 + pad; *y0 = by0 - pad; *y1 = by1 + pad;
-    return true;
-}
-
-// Bins the shapes by tile.  Returns false when binning would not pay (few shapes, or lists too long).
-bool bin_shapes(const cg_grid* g, const cg_shape* shapes, int nshapes, const double* pts, std::vector<int>* off, std::vector<int>* list,
-                std::vector<int>* wide) {
-    static const int min_shapes = [] { const char* e = getenv("CG_MASK_BIN_MIN"); return e ? atoi(e) : 8; }();
-    if (nshapes < min_shapes) return false;
-    const int tn_i = (g->nx + MASK_TILE - 1) / MASK_TILE, tn_j = (g->ny + MASK_TILE - 1) / MASK_TILE;
-    const size_t ntiles = (size_t)tn_i * tn_j;
-    if (ntiles > (size_t)INT32_MAX / 2) return false;
-    const size_t wide_area = std::max<size_t>(64, ntiles / 64);
-    struct Range { int i0, i1, j0, j1; };                       // tiles [i0, i1] x [j0, j1]; i1 < i0: none
-    std::vector<Range> rg((size_t)nshapes);
-    off->assign(ntiles + 1, 0); wide->clear();
-    size_t total = 0;
-    for (int s = 0; s < nshapes; s++) {
-        double x0, x1, y0, y1;
-        Range r{0, tn_i - 1, 0, tn_j - 1};
-        if (shape_box(shapes[s], pts, &x0, &x1, &y0, &y1)) {
-            if (x1 < x0 || y1 < y0) { rg[s] = Range{0, -1, 0, -1}; continue; }
-            // cell centres are (i + 0.5) * dx: one cell of slack on each side
-            const double ci0 = std::floor(x0 / g->dx - 0.5) - 1 - g->i0, ci1 = std::ceil(x1 / g->dx - 0.5) + 1 - g->i0;
-            const double cj0 = std::floor(y0 / g->dy - 0.5) - 1, cj1 = std::ceil(y1 / g->dy - 0.5) + 1;
-            if (ci1 < 0 || cj1 < 0 || ci0 > g->nx - 1 || cj0 > g->ny - 1) { rg[s] = Range{0, -1, 0, -1}; continue; }
-            r.i0 = (int)std::max(0.0, ci0) / MASK_TILE; r.i1 = (int)std::min((double)g->nx - 1, ci1) / MASK_TILE;
-            r.j0 = (int)std::max(0.0, cj0) / MASK_TILE; r.j1 = (int)std::min((double)g->ny - 1, cj1) / MASK_TILE;
-        }
-        const size_t area = (size_t)(r.i1 - r.i0 + 1) * (r.j1 - r.j0 + 1);
-        if (area > wide_area) { wide->push_back(s); rg[s] = Range{0, -1, 0, -1}; continue; }
-        rg[s] = r; total += area;
-        if (total > ((size_t)1 << 27)) return false;
-        for (int ti = r.i0; ti <= r.i1; ti++) for (int tj = r.j0; tj <= r.j1; tj++) (*off)[(size_t)ti * tn_j + tj + 1]++;
-    }
-    if (wide->size() > 64) return false;                        // every cell would walk them all anyway
-    for (size_t t = 0; t < ntiles; t++) (*off)[t + 1] += (*off)[t];
-    list->assign(std::max<size_t>(total, 1), 0);
-    std::vector<int> fill(off->begin(), off->end() - 1);
-    for (int s = 0; s < nshapes; s++) {
-        const Range& r = rg[s];
-        for (int ti = r.i0; ti <= r.i1; ti++) for (int tj = r.j0; tj <= r.j1; tj++) (*list)[fill[(size_t)ti * tn_j + tj]++] = s;
-    }
-    return true;
-}
-}  // namespace
-
 int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const double* pts, int npts, int* mask_id) {
     NEED_H(g);
     if (!mask_id || nshapes < 0 || npts < 0 || (nshapes > 0 && !shapes) || (npts > 0 && !pts))
@@ -1385,25 +1303,48 @@ int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const d
     HIPCHK(g, hipMalloc(&d_pts, std::max(1, npts) * 2 * sizeof(double)));
     if (nshapes) HIPCHK(g, hipMemcpyAsync(d_sh, shapes, nshapes * sizeof(Shape), hipMemcpyHostToDevice, g->stream));
     if (npts) HIPCHK(g, hipMemcpyAsync(d_pts, pts, (size_t)npts * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
-    std::vector<int> off, list, wide;
-    int* d_bins = nullptr;                                      // tile offsets, tile lists, wide shapes
+    // From a handful of shapes on they are binned by tile, on the device (cg_mask_bin.hip.h): count, scan, fill.  The one
+    // number the host needs in between is the length of the lists.
+    static const int min_shapes = [] { const char* e = getenv("CG_MASK_BIN_MIN"); return e ? atoi(e) : 8; }();
+    const int tn_i = (g->nx + MASK_TILE - 1) / MASK_TILE, tn_j = (g->ny + MASK_TILE - 1) / MASK_TILE;
+    const size_t ntiles = (size_t)tn_i * tn_j;
+    constexpr int WIDE_CAP = 64;                                // more wide shapes than this: every cell would walk them all anyway
+    char* d_bin = nullptr; int* d_list = nullptr;
     ProfScope ps(g, CG_K_MASK);
-    if (bin_shapes(g, shapes, nshapes, pts, &off, &list, &wide)) {
-        const size_t no = off.size(), nl = list.size(), nw = std::max<size_t>(wide.size(), 1);
-        HIPCHK(g, hipMalloc(&d_bins, (no + nl + nw) * sizeof(int)));
-        HIPCHK(g, hipMemcpyAsync(d_bins, off.data(), no * sizeof(int), hipMemcpyHostToDevice, g->stream));
-        HIPCHK(g, hipMemcpyAsync(d_bins + no, list.data(), nl * sizeof(int), hipMemcpyHostToDevice, g->stream));
-        if (!wide.empty()) HIPCHK(g, hipMemcpyAsync(d_bins + no + nl, wide.data(), wide.size() * sizeof(int), hipMemcpyHostToDevice, g->stream));
-        const int tn_j = (g->ny + MASK_TILE - 1) / MASK_TILE;
-        hipLaunchKernelGGL(k_mask_shapes_binned, dim3((unsigned)(no - 1)), dim3(256), 0, g->stream, g->nx, g->ny, g->i0, g->dx, g->dy, d_sh, d_pts,
-                           tn_j, d_bins, d_bins + no, d_bins + no + nl, (int)wide.size(), buf);
-    } else {
+    bool binned = false;
+    if (nshapes >= min_shapes && ntiles <= (size_t)INT32_MAX / 2) {
+        // one allocation: ranges | counts | offsets | cursors | wide | counters
+        const size_t b_rg = (size_t)nshapes * sizeof(TileRange), b_cnt = ntiles * sizeof(int), b_off = (ntiles + 1) * sizeof(int);
+        const size_t o_cnt = (b_rg + 15) & ~(size_t)15, o_off = o_cnt + ((b_cnt + 15) & ~(size_t)15), o_cur = o_off + ((b_off + 15) & ~(size_t)15);
+        const size_t o_wide = o_cur + ((b_cnt + 15) & ~(size_t)15), o_ctr = o_wide + WIDE_CAP * sizeof(int), total_b = o_ctr + 4 * sizeof(unsigned);
+        HIPCHK(g, hipMalloc(&d_bin, total_b));
+        TileRange* d_rg = (TileRange*)d_bin; int* d_cnt = (int*)(d_bin + o_cnt); int* d_off = (int*)(d_bin + o_off); int* d_cur = (int*)(d_bin + o_cur);
+        int* d_wide = (int*)(d_bin + o_wide); unsigned* d_ctr = (unsigned*)(d_bin + o_ctr);
+        HIPCHK(g, hipMemsetAsync(d_cnt, 0, b_cnt, g->stream));
+        HIPCHK(g, hipMemsetAsync(d_ctr, 0, 4 * sizeof(unsigned), g->stream));
+        const unsigned wide_area = (unsigned)std::max<size_t>(64, ntiles / 64);
+        hipLaunchKernelGGL(k_shape_ranges, dim3((unsigned)((nshapes + 255) / 256)), dim3(256), 0, g->stream, g->nx, g->ny, g->i0, g->dx, g->dy, d_sh, nshapes,
+                           d_pts, tn_i, tn_j, wide_area, d_rg, d_cnt, d_wide, WIDE_CAP, d_ctr);
+        hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, g->stream, d_cnt, (int)ntiles, d_off);
+        HIPCHK(g, hipGetLastError());
+        unsigned ctr[4] = {0, 0, 0, 0};
+        HIPCHK(g, hipMemcpyAsync(ctr, d_ctr, sizeof ctr, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(g, hipStreamSynchronize(g->stream));
+        if (!ctr[2] && ctr[0] <= (unsigned)WIDE_CAP && ctr[1] <= (1u << 27)) {
+            HIPCHK(g, hipMalloc(&d_list, std::max<size_t>(ctr[1], 1) * sizeof(int)));
+            HIPCHK(g, hipMemcpyAsync(d_cur, d_off, b_cnt, hipMemcpyDeviceToDevice, g->stream));
+            hipLaunchKernelGGL(k_shape_fill, dim3((unsigned)((nshapes + 255) / 256)), dim3(256), 0, g->stream, d_rg, nshapes, tn_j, d_cur, d_list);
+            hipLaunchKernelGGL(k_mask_shapes_tiles, dim3((unsigned)ntiles), dim3(256), 0, g->stream, g->nx, g->ny, g->i0, g->dx, g->dy, d_sh, d_pts,
+                               tn_j, d_off, d_list, d_wide, (int)ctr[0], buf);
+            binned = true;
+        }
+    }
+    if (!binned)
         hipLaunchKernelGGL(k_mask_shapes, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, g->nx, g->ny, g->i0, g->dx, g->dy, d_sh, nshapes,
                            d_pts, buf);
-    }
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipStreamSynchronize(g->stream));
-    (void)hipFree(d_sh); (void)hipFree(d_pts); if (d_bins) (void)hipFree(d_bins);
+    (void)hipFree(d_sh); (void)hipFree(d_pts); if (d_bin) (void)hipFree(d_bin); if (d_list) (void)hipFree(d_list);
     return CG_OK;
 }
 

@@ -196,3 +196,49 @@ def test_edge_cases():
     with pytest.raises(fem.ColGridError):
         g.deposit_general(None, 4, 10, 1.0)          # Rx = 3, Ry = 5
     g.close()
+
+
+def test_c5_first_steps_at_32768():
+    """32768 x 32768 (configuration C5's size, 1.07 G columns): the first 12 steps of its flow -- vertical runs that go out
+    fused, lateral steps on the lean streaming kernels -- against a replay of the same steps through the other kernel
+    family (statistics on: one launch per step, gathering lateral kernels, the reference's double arithmetic throughout):
+    same checksum after the last step, same cross-sections.  The three masks of these steps are periodic (32, 24 and 32
+    cells), so away from the domain edges the grid repeats every 96 cells in both directions."""
+    import torch
+    import fem_amd as fem
+    from fem_amd import flows
+    n = 32768
+    free, _total = torch.cuda.mem_get_info()
+    if free < 120 * (1 << 30):
+        pytest.skip("needs 120 GiB of free device memory")
+    flow = flows.flow_c5()[:12]
+    assert {s["mask"] for s in flow if s["mask"]} == {"M", "Mc", "Mshift"}
+    specs = flows.mask_specs(2.0 * n)
+    g = fem.ColumnGrid(dx=2.0, dy=2.0, slab=(n, n, 0, n))
+    g.keep_step_snapshots = False
+    gm, _ = _masks(fem, flows, g, None, specs, ["M", "Mc", "Mshift"], n)
+    lines_i = [4800, 4800 + 96 * 100, 4800 + 96 * 250, n - 1]
+    lines_j = [4801, 4801 + 96 * 7, 0]
+
+    def run(stats):
+        g.createNewGrid()
+        g.stats_enable(stats)
+        for s in flow:
+            flows.apply_step(g, s, gm)
+        out = (g.checksum(), g.maxHeight(), g.Lmax, g.slices("YZ", lines_i), g.slices("XZ", lines_j))
+        g.stats_enable(False)
+        return out
+
+    a = run(False)
+    b = run(True)
+    assert a[:3] == b[:3]
+    for x, y in zip(a[3] + a[4], b[3] + b[4]):
+        np.testing.assert_array_equal(x, y)
+    # translation symmetry (period 96 cells), away from the edges
+    ln, mat, zp = a[3]
+    np.testing.assert_array_equal(ln[0], ln[1]); np.testing.assert_array_equal(zp[0], zp[2]); np.testing.assert_array_equal(mat[1], mat[2])
+    inner = slice(960, 960 + 96 * 300)
+    np.testing.assert_array_equal(ln[0][inner], ln[0][960 + 96:960 + 96 * 301])
+    ln2, mat2, zp2 = a[4]
+    np.testing.assert_array_equal(ln2[0][inner], ln2[1][inner]); np.testing.assert_array_equal(zp2[0][inner], zp2[1][inner])
+    g.close()
