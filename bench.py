@@ -311,7 +311,8 @@ def main():
                 close_run()
             if kd.startswith("k_vertical") and fusing:
                 run.append(idx)
-                if len(run) == FUSE_MAX or slice_idx:
+                # (the run that starts on the reset grid goes out as one table look-up of up to 16 steps)
+                if len(run) == (16 if run[0] == 0 else FUSE_MAX) or slice_idx:
                     close_run()
             else:
                 close_run()

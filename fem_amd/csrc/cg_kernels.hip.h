@@ -802,6 +802,74 @@ __global__ __launch_bounds__(256) void k_vertical_fused(GridView g, const FusedO
 }
 
 // ------------------------------------------------------------------------------------------
+// A run of vertical steps on a grid that has just been reset
+// ------------------------------------------------------------------------------------------
+// Every column of a reset grid is empty, and a vertical step changes a column from that column and its mask byte alone:
+// after a run of such steps a column's state is a function of which of the run's masks are open there and of nothing
+// else.  With NM distinct masks in the run there are 2^NM such classes; the host works the one column of each class out
+// (the literal reference arithmetic on one column, see fresh_run_table in colgrid.hip) and this kernel only looks the
+// class of every column up: mask bytes in, the top record and what each deposit of the run pushed into its plane out.
+// The start of every rebuild -- createNewGrid, substrate, blanket films, the first patterning etches -- runs like this,
+// at the rate of its stores.
+constexpr int FRESH_MAX_STEPS = 16;        // steps of such a run (the queue of a reset grid may grow this long)
+constexpr int FRESH_MAX_MASKS = 3;         // distinct masks in it
+constexpr int FRESH_MAX_DEP = 12;          // deposits (each owns a plane)
+struct FreshTab {
+    uint32_t top[1 << FRESH_MAX_MASKS];                         // per class: the final top record (0: the column ends empty)
+    uint32_t pushed[FRESH_MAX_DEP][1 << FRESH_MAX_MASKS];       // per deposit and class: the record stored into that deposit's plane, 0 = none
+    int plane[FRESH_MAX_DEP];
+    int ndep, nmask, rt_shift, pad_;
+    const uint8_t* mask[FRESH_MAX_MASKS];
+};
+
+// A thread owns FRESH_U groups of 4 columns, 256 groups apart (a launch that mostly stores runs faster that way: measured
+// +40 % for the write-only first deposit); all mask loads go out first.
+constexpr int FRESH_U = 4;
+template <int NM>
+__global__ __launch_bounds__(256) void k_vertical_fresh(GridView g, const FreshTab T) {
+    constexpr int NC = 1 << NM;
+    __shared__ uint32_t s_tab[(1 + FRESH_MAX_DEP) * NC];          // [0..NC) tops, then NC entries per deposit
+    for (int e = threadIdx.x; e < (1 + T.ndep) * NC; e += 256) s_tab[e] = e < NC ? T.top[e] : T.pushed[e / NC - 1][e % NC];
+    __syncthreads();
+    const size_t ngroups = g.N >> 2;
+    const size_t gbase = (size_t)blockIdx.x * (256 * FRESH_U) + threadIdx.x;
+    unsigned w[FRESH_U][NM > 0 ? NM : 1];
+#pragma unroll
+    for (int u = 0; u < FRESH_U; u++) {
+        const size_t gi = gbase + (size_t)u * 256;
+#pragma unroll
+        for (int m = 0; m < NM; m++) w[u][m] = gi < ngroups ? *(const unsigned*)(T.mask[m] + (gi << 2)) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < FRESH_U; u++) {
+        const size_t gi = gbase + (size_t)u * 256;
+        if (gi >= ngroups) continue;
+        const size_t c0 = gi << 2;
+        unsigned cls[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < NM; m++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) cls[j] |= ((w[u][m] >> (8 * j)) & 0xffu) ? (1u << m) : 0u;
+        }
+        u32x4 nv;
+#pragma unroll
+        for (int j = 0; j < 4; j++) nv[j] = s_tab[cls[j]];
+        st_rec4(g.top_w + c0, nv);
+        for (int d = 0; d < T.ndep; d++) {
+            u32x4 pv;
+#pragma unroll
+            for (int j = 0; j < 4; j++) pv[j] = s_tab[(1 + d) * NC + cls[j]];
+            uint32_t* at = g.rec + (size_t)T.plane[d] * g.N + c0;
+            if (pv[0] && pv[1] && pv[2] && pv[3]) st_rec4(at, pv);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (pv[j]) at[j] = pv[j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // lateral-stencil steps: dilation / erosion of the top-height map + per-column update
 // ------------------------------------------------------------------------------------------
 //

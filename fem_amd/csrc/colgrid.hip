@@ -1013,6 +1013,90 @@ static void launch_vertical(cg_grid* g, const uint8_t* mask, int mat, double t, 
 // lengths, the pristine state) is settled when the step is queued; a deposit that could meet a full column, outgrow
 // the Lmax the caller sees or find no plane to spare is not queued: it flushes and takes the one-step protocol.
 namespace {
+// One column of the reference on the host, in the device's record format: _depoAtTop_ (cg1:397-426) and _applyEtchAt
+// (cg1:553-589) with the literal quantiser.  `planes` is what the deposits of the run have pushed at this column so far.
+struct HostColumn {
+    uint32_t top = 0;
+    std::map<int, uint32_t> planes;
+    static uint32_t z1(uint32_t r) { return r & 0xffffu; }
+    static int mat(uint32_t r) { return (int)((r >> 16) & 255u); }
+    static int lnk(uint32_t r) { return (int)(r >> LNK_SHIFT); }
+    static uint32_t make(uint32_t q, int m, int l) { return (q & 0xffffu) | ((uint32_t)(m & 255) << 16) | REC_LAYER | ((uint32_t)l << LNK_SHIFT); }
+    uint32_t below(uint32_t r) const { const int l = lnk(r); if (l == LNK_NONE) return 0; auto it = planes.find(l); return it == planes.end() ? 0 : it->second; }
+    // returns what was pushed into plane P (0: nothing)
+    uint32_t deposit(int m, double t, int P, double zs) {
+        if (!(t > 0)) return 0;
+        const uint32_t q = quantz_host((double)z1(top) * zs + t, zs);
+        if (top != 0 && mat(top) == m) { top = (top & 0xffff0000u) | q; return 0; }
+        const uint32_t old = top;
+        top = make(q, m, old != 0 ? P : LNK_NONE);
+        if (old != 0) planes[P] = old;
+        return old;
+    }
+    void etch(int m, double t, double zs) {
+        const bool isAll = (m == 255);
+        double remaining = t;
+        while (remaining > CG_EPS && top != 0) {
+            if (!isAll && mat(top) != m) break;
+            const uint32_t b = below(top);
+            const double zt = (double)z1(top) * zs, zb = (double)z1(b) * zs, thick = zt - zb;
+            if (remaining < thick - CG_EPS) { top = (top & 0xffff0000u) | quantz_host(zt - remaining, zs); break; }
+            remaining -= thick;
+            top = b;                                           // (a reset grid holds no gaps: nothing else to drop)
+        }
+    }
+};
+
+// The run `ops` starts on a reset grid.  When it has at most FRESH_MAX_MASKS distinct masks its outcome per column is one
+// of 2^masks columns worked out here; k_vertical_fresh stores them.  Returns false when the run does not qualify.
+bool fresh_run(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, int* rc) {
+    static const bool off = getenv("CG_NO_FRESH_RUN") != nullptr;
+    *rc = CG_OK;
+    if (off || ops.empty() || !ops[0].fresh || (int)ops.size() > FRESH_MAX_STEPS || g->N % 4 != 0) return false;
+    FreshTab T = {};
+    std::vector<int> mask_of(ops.size(), -1);
+    for (size_t k = 0; k < ops.size(); k++) {
+        if (!ops[k].mask) continue;
+        int m = -1;
+        for (int q = 0; q < T.nmask; q++) if (T.mask[q] == ops[k].mask) m = q;
+        if (m < 0) { if (T.nmask == FRESH_MAX_MASKS) return false; m = T.nmask; T.mask[T.nmask++] = ops[k].mask; }
+        mask_of[k] = m;
+    }
+    for (size_t k = 0; k < ops.size(); k++)
+        if (!ops[k].etch) { if (T.ndep == FRESH_MAX_DEP) return false; T.plane[T.ndep++] = ops[k].P; }
+    const int ncls = 1 << T.nmask;
+    for (int c = 0; c < ncls; c++) {
+        HostColumn col;
+        int d = 0;
+        for (size_t k = 0; k < ops.size(); k++) {
+            const bool open = mask_of[k] < 0 || ((c >> mask_of[k]) & 1);
+            if (ops[k].etch) { if (open) col.etch(ops[k].mat, ops[k].t, g->zscale); continue; }
+            T.pushed[d][c] = open ? col.deposit(ops[k].mat, ops[k].t, ops[k].P, g->zscale) : 0u;
+            d++;
+        }
+        T.top[c] = col.top;
+        // a record the final chain does not reach need not be stored (plane slots outside a column's chain are unspecified)
+        for (int q = 0; q < T.ndep; q++) {
+            bool reached = false;
+            for (uint32_t r = col.top; r != 0 && HostColumn::lnk(r) != LNK_NONE; r = col.below(r)) if (HostColumn::lnk(r) == T.plane[q]) { reached = true; break; }
+            if (!reached) T.pushed[q][c] = 0;
+        }
+    }
+    T.rt_shift = -1;
+    const size_t nb = (g->N / 4 + (size_t)256 * FRESH_U - 1) / ((size_t)256 * FRESH_U);
+    ProfScope ps(g, CG_K_VERTICAL_FUSED);
+    const dim3 grid((unsigned)std::max<size_t>(1, nb));
+    switch (T.nmask) {
+    case 0: hipLaunchKernelGGL(k_vertical_fresh<0>, grid, dim3(256), 0, g->stream, view(g), T); break;
+    case 1: hipLaunchKernelGGL(k_vertical_fresh<1>, grid, dim3(256), 0, g->stream, view(g), T); break;
+    case 2: hipLaunchKernelGGL(k_vertical_fresh<2>, grid, dim3(256), 0, g->stream, view(g), T); break;
+    default: hipLaunchKernelGGL(k_vertical_fresh<3>, grid, dim3(256), 0, g->stream, view(g), T); break;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) *rc = fail(g, CG_ERR_HIP, "k_vertical_fresh: %s", hipGetErrorString(e));
+    return true;
+}
+
 int flush_vertical(cg_grid* g) {
     if (g->vq.empty()) return CG_OK;
     std::vector<cg_grid::VQOp> ops; ops.swap(g->vq);
@@ -1022,6 +1106,19 @@ int flush_vertical(cg_grid* g) {
         if (o.etch) launch_vertical<true>(g, o.mask, o.mat, o.t, -1, false);
         else launch_vertical<false>(g, o.mask, o.mat, o.t, o.P, o.fresh);
         HIPCHK(g, hipGetLastError());
+        return CG_OK;
+    }
+    if (ops[0].fresh) {
+        int rcf = 0;
+        if (fresh_run(g, ops, &rcf)) return rcf;            // a run on a reset grid: one column per mask class, looked up
+    }
+    if ((int)ops.size() > FUSE_MAX) {
+        // (a long run that the class form could not take after all: in pieces)
+        for (size_t b = 0; b < ops.size(); b += FUSE_MAX) {
+            g->vq.assign(ops.begin() + b, ops.begin() + std::min(ops.size(), b + FUSE_MAX));
+            if (b > 0) g->vq[0].fresh = false;
+            int rcp = flush_vertical(g); if (rcp) return rcp;
+        }
         return CG_OK;
     }
     FusedOps F = {};
@@ -1079,7 +1176,9 @@ int enqueue_vertical(cg_grid* g, bool etch, const uint8_t* mask, int mat, double
     }
     g->len_valid = false;
     g->vq.push_back(op);
-    if ((int)g->vq.size() >= FUSE_MAX) return flush_vertical(g);
+    // the run of a reset grid goes out as a table look-up whatever its length (fresh_run); any other run holds FUSE_MAX steps
+    const int cap = g->vq[0].fresh ? FRESH_MAX_STEPS : FUSE_MAX;
+    if ((int)g->vq.size() >= cap) return flush_vertical(g);
     return CG_OK;
 }
 }  // namespace
