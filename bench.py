@@ -357,8 +357,16 @@ def main():
                     traffic_src = {"file": os.path.relpath(tpath, ROOT), "git_blob": git_blob_hash(tpath)}
         if dom:
             achieved = cand[dom]["GBps"]
+            note = None
+            if dom == "k_vertical_fused":
+                # only fused launches ran (a flow of vertical steps): the sum of the fused steps' bytes over the launch time
+                # is not a memory rate (it passes the peak), so the rate given is the measured traffic's, or none
+                achieved = cand[dom].get("traffic_GBps")
+                note = ("every launch applies a run of vertical steps in one pass; achieved = PMC traffic per launch / launch time"
+                        if achieved is not None else
+                        "every launch applies a run of vertical steps in one pass: no per-step memory rate exists and no PMC traffic file covers this workload")
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "frac": round(achieved / 8000.0, 4) if achieved is not None else None, "note": note, "traffic": traffic, "traffic_source": traffic_src,
                         "launches": cand[dom]["launches"], "ms_avg": cand[dom]["ms_avg"], "fused_steps_per_launch": (fused_steps / max(1, fused_launches)) if dom == "k_vertical_fused" else 1,
                         "algorithmic_bytes_per_launch": int(kbytes[dom] / max(1, cand[dom]["launches"]))}
         total_alg = sum(step_bytes[(k + q) % len(flow)] for q in range(total_steps))

@@ -2155,26 +2155,44 @@ __device__ __forceinline__ bool layer_exposed(const GridView& g, const Ghost& gh
     return false;
 }
 
-// cand[c] = 1 while column c still has an unmarked node of matId: the sweeps skip the others
-// after reading one byte.
-static __global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+// cand[c]: bit 0 while column c still has an unmarked node of matId (the passes that spread marks skip the others
+// after reading one byte), bit 1 when it has any node of matId at all.  parent (may be null): the forest of
+// k_strip_union, every unmarked node of matId its own root to begin with; with it, block b also lists the columns it
+// found an unmarked node in, list[b*segcap ..] (segcap = the number of columns a block visits), counts[b] of them.
+static __global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh, int matId, uint8_t* __restrict__ cand, uint32_t* __restrict__ parent,
+                                                    uint32_t* __restrict__ list, uint32_t* __restrict__ counts, size_t segcap) {
+    __shared__ unsigned s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    // Runs of 256 columns are dealt to the blocks round by round, one place further (times 5) along every round: with a
+    // fixed deal a block would meet the same stretch of j in every row it visits, and patterns that run along i would
+    // give some blocks' lists many times the entries of others'.
+    const size_t chunks = (g.N + 255) / 256, rounds = (chunks + gridDim.x - 1) / gridDim.x;
+    for (size_t k = 0; k < rounds; k++) {
+        const size_t q = k * gridDim.x + (blockIdx.x + 5 * k) % gridDim.x;
+        const size_t c = q * 256 + threadIdx.x;
+        if (c >= g.N) continue;
         const int l = g.len[c];
         if (l == 0) { cand[c] = 0; continue; }
-        bool open_node = false;
+        bool open_node = false, node = false;
         const int i = (int)(c / g.ny), j = (int)(c - (size_t)i * g.ny);
         const unsigned topq = rec_z1(g.rec[(size_t)(l - 1) * g.N + c]);
         unsigned prev = 0;
         for (int k = 0; k < l; k++) {
             const uint32_t r = g.rec[(size_t)k * g.N + c];
             if (!rec_hole(r) && rec_mat(r) == matId) {
+                node = true;
                 if (layer_exposed(g, gh, i, j, prev, rec_z1(r), topq)) g.rec[(size_t)k * g.N + c] = r | REC_MARK;
-                else open_node = true;
+                else { open_node = true; if (parent) parent[(size_t)k * g.N + c] = (uint32_t)((size_t)k * g.N + c); }
             }
             prev = rec_z1(r);
         }
-        cand[c] = open_node ? 1 : 0;
+        cand[c] = (open_node ? 1 : 0) | (node ? 2 : 0);
+        if (open_node && parent) list[(size_t)blockIdx.x * segcap + atomicAdd(&s_n, 1u)] = (uint32_t)c;
+    }
+    if (parent) {
+        __syncthreads();
+        if (threadIdx.x == 0) counts[blockIdx.x] = s_n;
     }
 }
 
@@ -2193,7 +2211,7 @@ static __global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh
     int any = 0;
     for (size_t cc = (size_t)blockIdx.x * blockDim.x + threadIdx.x; cc < g.N; cc += stride) {
         const size_t c = reverse ? g.N - 1 - cc : cc;
-        if (!cand[c]) continue;
+        if (!(cand[c] & 1)) continue;
         const int l = g.len[c];
         bool open_node = false;
         const int i = (int)(c / g.ny), j = (int)(c - (size_t)i * g.ny);
@@ -2221,7 +2239,134 @@ static __global__ __launch_bounds__(256) void k_strip_flood(GridView g, Ghost gh
             if (hit) { g.rec[(size_t)k * g.N + c] = r | REC_MARK; any = 1; }
             else open_node = true;
         }
-        if (!open_node) cand[c] = 0;
+        if (!open_node) cand[c] = 2;
+    }
+    if (any) *changed = 1;
+}
+
+// ---- the same closure by connected components: a fixed number of launches, whatever the shape of the material ----
+// Node (c, k) -- interval k of column c -- has the number k*N + c (the host checks that these stay below 2^32 - 1), and
+// parent[] is a union-find forest over the unmarked nodes of matId in which a link always points to a higher number,
+// so there are no cycles whatever the interleaving.  The highest number of all, UF_MARKED, stands for "marked": it has
+// no slot in parent[] and is a root by definition.  k_strip_union joins every pair of overlapping unmarked nodes in
+// neighbouring columns (each pair once: towards i+1 and j+1) and hangs a node that overlaps a marked one under
+// UF_MARKED; afterwards the tree of UF_MARKED holds exactly the closure, and k_strip_spread marks every node whose root
+// it is.  On a decomposed domain the forest is built once; after every exchange k_strip_ghost hangs the border nodes
+// that touch a marked node of a neighbour's ghost row under UF_MARKED and k_strip_spread runs again.
+constexpr uint32_t UF_MARKED = 0xffffffffu;
+__device__ __forceinline__ uint32_t uf_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
+    if (x == UF_MARKED) return x;
+    uint32_t p = uf_load(parent + x);
+    while (p != x) {                                   // halve the path on the way up: x is not a root and never becomes one again
+        if (p == UF_MARKED) return p;
+        const uint32_t gp = uf_load(parent + p);
+        if (gp != p) __hip_atomic_store(parent + x, gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = p; p = gp;
+    }
+    return x;
+}
+__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
+    a = uf_find(parent, a); b = uf_find(parent, b);
+    while (a != b) {
+        if (a > b) { const uint32_t t = a; a = b; b = t; }                 // the lower root goes under the higher one
+        const uint32_t old = atomicCAS(parent + a, a, b);                   // ... if it still is a root
+        if (old == a) return;
+        a = uf_find(parent, old); b = uf_find(parent, b);
+    }
+}
+
+// Launched with the grid of k_strip_seed: block b works through the columns block b listed there, so every lane has a
+// column with an unmarked node to look at (such columns are few, and a pass over all columns would spend its time on
+// waves with two or three busy lanes).  A pair of unmarked nodes is met from both sides; the second meeting finds them
+// joined.  A marked node needs no visit of its own: the unmarked nodes around it come to it.
+static __global__ __launch_bounds__(256) void k_strip_union(GridView g, int matId, const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts, size_t segcap,
+                                                     uint32_t* __restrict__ parent) {
+    const unsigned n = counts[blockIdx.x];
+    const uint32_t* mine = list + (size_t)blockIdx.x * segcap;
+    for (unsigned idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        const size_t c = mine[idx];
+        const int i = (int)(c / g.ny), j = (int)(c - (size_t)i * g.ny);
+        const bool okn[4] = {i + 1 < g.nx, i > 0, j + 1 < g.ny, j > 0};
+        const size_t nb[4] = {c + g.ny, c - g.ny, c + 1, c - 1};
+        const int l = g.len[c];
+        unsigned prev = 0;
+        for (int k = 0; k < l; k++) {
+            const uint32_t r = g.rec[(size_t)k * g.N + c];
+            const unsigned a0 = prev, a1 = rec_z1(r);
+            prev = a1;
+            if (rec_hole(r) || (r & REC_MARK) || rec_mat(r) != matId) continue;
+            const uint32_t ida = (uint32_t)((size_t)k * g.N + c);
+            bool done = false;                           // under the mark: whoever else touches this node finds that out from its own side
+            for (int d = 0; d < 4 && !done; d++) {
+                if (!okn[d]) continue;
+                const size_t nn = nb[d];
+                const int ln = g.len[nn];
+                unsigned b0 = 0;
+                for (int kk = 0; kk < ln; kk++) {
+                    const uint32_t rb = g.rec[(size_t)kk * g.N + nn];
+                    const unsigned b1 = rec_z1(rb);
+                    if (!rec_hole(rb) && rec_mat(rb) == matId && a0 < b1 && b0 < a1) {                                  // cg1:879
+                        if (rb & REC_MARK) { uf_union(parent, ida, UF_MARKED); done = true; break; }
+                        uf_union(parent, ida, (uint32_t)((size_t)kk * g.N + nn));
+                    }
+                    b0 = b1;
+                    if (b0 >= a1) break;
+                }
+            }
+        }
+    }
+}
+
+// border rows only: one thread per column of row 0 and one per column of row nx-1 (a slab of one row is seen by both)
+static __global__ __launch_bounds__(256) void k_strip_ghost(GridView g, Ghost gh, int matId, const uint8_t* __restrict__ cand, uint32_t* __restrict__ parent) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * g.ny) return;
+    const int side = e >= g.ny, j = e - side * g.ny;
+    if (side ? !gh.up_len : !gh.lo_len) return;
+    const int i = side ? g.nx - 1 : 0;
+    const size_t c = (size_t)i * g.ny + j;
+    if (!(cand[c] & 1)) return;
+    const ColRef n = column_ref(g, gh, side ? g.nx : -1, j);
+    if (!n.ok) return;
+    const int l = g.len[c];
+    unsigned prev = 0;
+    for (int k = 0; k < l; k++) {
+        const size_t id = (size_t)k * g.N + c;
+        const uint32_t r = g.rec[id];
+        const unsigned a0 = prev, a1 = rec_z1(r);
+        prev = a1;
+        if (rec_hole(r) || (r & REC_MARK) || rec_mat(r) != matId) continue;
+        unsigned b0 = 0;
+        for (int kk = 0; kk < n.len; kk++) {
+            const uint32_t rb = n.rec[(size_t)kk * n.stride];
+            const unsigned b1 = rec_z1(rb);
+            if ((rb & REC_MARK) && !rec_hole(rb) && rec_mat(rb) == matId && a0 < b1 && b0 < a1) { uf_union(parent, (uint32_t)id, UF_MARKED); break; }
+            b0 = b1;
+            if (b0 >= a1) break;
+        }
+    }
+}
+
+// (the grid of k_strip_seed again)
+static __global__ __launch_bounds__(256) void k_strip_spread(GridView g, int matId, uint8_t* __restrict__ cand, const uint32_t* __restrict__ list,
+                                                      const uint32_t* __restrict__ counts, size_t segcap, uint32_t* __restrict__ parent, int* __restrict__ changed) {
+    const unsigned n = counts[blockIdx.x];
+    const uint32_t* mine = list + (size_t)blockIdx.x * segcap;
+    int any = 0;
+    for (unsigned idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        const size_t c = mine[idx];
+        if (!(cand[c] & 1)) continue;
+        const int l = g.len[c];
+        bool open_node = false;
+        for (int k = 0; k < l; k++) {
+            const size_t id = (size_t)k * g.N + c;
+            const uint32_t r = g.rec[id];
+            if (rec_hole(r) || (r & REC_MARK) || rec_mat(r) != matId) continue;
+            if (uf_find(parent, (uint32_t)id) == UF_MARKED) { g.rec[id] = r | REC_MARK; any = 1; }
+            else open_node = true;
+        }
+        if (!open_node) cand[c] = 2;
     }
     if (any) *changed = 1;
 }

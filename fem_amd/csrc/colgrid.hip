@@ -157,6 +157,9 @@ struct cg_grid {
     size_t seed_stride = 0, seed_off = 0; int seed_rows = 0; bool seed_lo = false, seed_hi = false;
     int* d_bbox = nullptr;
     uint8_t* cand = nullptr;                               // strip_connected: columns that still hold an unmarked node
+    uint32_t* uf = nullptr; size_t uf_cap = 0;             // strip_connected: the union-find forest over the nodes (uf_cap words), kept until cg_release_scratch
+    bool uf_on = false, uf_joined = false;                 // this flood runs on the forest / the forest has been joined
+    uint32_t* uf_list = nullptr; uint32_t* uf_counts = nullptr; size_t uf_segcap = 0;    // (inside uf) columns with an unmarked node, listed per seed block
     // vertical steps queued for one fused launch (see k_vertical_fused): nothing has looked at the grid since the first
     struct VQOp { const uint8_t* mask; bool etch; int mat; double t; int P; bool fresh; };
     std::vector<VQOp> vq;
@@ -1266,6 +1269,7 @@ int cg_destroy(cg_grid* g) {
     if (g->d_sum) (void)hipFree(g->d_sum);
     if (g->d_bbox) (void)hipFree(g->d_bbox);
     if (g->cand) (void)hipFree(g->cand);
+    if (g->uf) (void)hipFree(g->uf);
     if (g->d_ald_taps) (void)hipFree(g->d_ald_taps);
     free_alt(g, 0); free_alt(g, 1); drop_seeds(g);
     if (g->d_stats) (void)hipFree(g->d_stats);
@@ -1767,8 +1771,29 @@ int cg_strip_seed(cg_grid* g, int mat, int planes, const void* ghost_lower, cons
     g->pend.active = false;
     int rc = ensure_whole(g); if (rc) return rc;
     if (!g->cand) HIPCHK(g, hipMalloc(&g->cand, std::max<size_t>(g->N, 16)));
+    // The flood runs on a union-find forest over the nodes (interval k of column c = number k*N + c) when those numbers
+    // fit 32 bits and the forest fits the memory; sweeps to the fixpoint otherwise (CG_STRIP_SWEEPS=1 asks for them).
+    // Behind the forest: the seed blocks' lists of columns with an unmarked node, and the lengths of those lists.
+    g->uf_on = false; g->uf_joined = false;
+    const unsigned nblk = blocks_for(g->N);
+    const size_t nodes = (size_t)std::max(1, std::min(g->len_bound, g->lmax)) * g->N;
+    const size_t segcap = ((g->N + (size_t)nblk * 256 - 1) / ((size_t)nblk * 256)) * 256;
+    const size_t words = nodes + (size_t)nblk * segcap + nblk;
+    const char* sw = getenv("CG_STRIP_SWEEPS");
+    if (!(sw && sw[0] == '1') && nodes < 0xffffffffull) {          // (the highest 32-bit number stands for "marked")
+        if (g->uf_cap < words) {
+            if (g->uf) { (void)hipFree(g->uf); g->uf = nullptr; g->uf_cap = 0; }
+            if (hipMalloc(&g->uf, words * sizeof(uint32_t)) == hipSuccess) g->uf_cap = words;
+            else { (void)hipGetLastError(); g->uf = nullptr; }
+        }
+        g->uf_on = g->uf != nullptr;
+    }
+    g->uf_list = g->uf_on ? g->uf + nodes : nullptr;
+    g->uf_counts = g->uf_on ? g->uf_list + (size_t)nblk * segcap : nullptr;
+    g->uf_segcap = segcap;
     ProfScope ps(g, CG_K_OTHER);
-    hipLaunchKernelGGL(k_strip_seed, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), make_ghost(g, planes, ghost_lower, ghost_upper), mat, g->cand);
+    hipLaunchKernelGGL(k_strip_seed, dim3(nblk), dim3(256), 0, g->stream, view(g), make_ghost(g, planes, ghost_lower, ghost_upper), mat, g->cand,
+                       g->uf_on ? g->uf : nullptr, g->uf_list, g->uf_counts, segcap);
     HIPCHK(g, hipGetLastError());
     return CG_OK;
 }
@@ -1781,6 +1806,23 @@ int cg_strip_sweep(cg_grid* g, int mat, int planes, const void* ghost_lower, con
     const dim3 grid(blocks_for(g->N)), blk(256);
     const Ghost gh = make_ghost(g, planes, ghost_lower, ghost_upper);
     int any = 0;
+    if (g->uf_on) {
+        // the pieces of the material are joined once (and the ones that touch a seed hung under the mark); each call
+        // then hangs what touches a marked node of the ghost rows under the mark too and marks every node whose root
+        // the mark is: two launches the first time, one or two afterwards
+        if (!g->uf_joined) {
+            hipLaunchKernelGGL(k_strip_union, grid, blk, 0, g->stream, view(g), mat, g->uf_list, g->uf_counts, g->uf_segcap, g->uf);
+            g->uf_joined = true;
+        }
+        if (gh.lo_len || gh.up_len)
+            hipLaunchKernelGGL(k_strip_ghost, dim3((2 * (unsigned)g->ny + 255) / 256), blk, 0, g->stream, view(g), gh, mat, g->cand, g->uf);
+        HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+        hipLaunchKernelGGL(k_strip_spread, grid, blk, 0, g->stream, view(g), mat, g->cand, g->uf_list, g->uf_counts, g->uf_segcap, g->uf, g->d_flags);
+        HIPCHK(g, hipGetLastError());
+        int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
+        if (changed) *changed = fl[0] ? 1 : 0;
+        return CG_OK;
+    }
     // Relax to the local fixpoint.  Sweeps go out four at a time, up and down the columns in turn, each with a flag word
     // of its own; the words are read back together and the flood is over when the last sweep of a batch changed nothing
     // (the closure is a fixpoint of every sweep, whichever way it runs).
@@ -2185,6 +2227,7 @@ int cg_release_scratch(cg_grid* g) {
     NEED_H(g);
     HIPCHK(g, hipStreamSynchronize(g->stream));
     free_alt(g, 0); free_alt(g, 1);
+    if (g->uf) { (void)hipFree(g->uf); g->uf = nullptr; g->uf_cap = 0; g->uf_on = false; }
     return CG_OK;
 }
 

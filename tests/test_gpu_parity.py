@@ -642,6 +642,37 @@ def test_strip_connected_along_a_serpentine():
     g.close()
 
 
+@pytest.mark.parametrize("seed,layers", [(11, 6), (12, 3), (13, 12)])
+def test_strip_flood_by_components_equals_sweeps(seed, layers, monkeypatch):
+    """strip_connected joins the pieces of the material in a union-find forest and hands the marks over the roots
+    (a fixed number of launches); CG_STRIP_SWEEPS=1 relaxes sweep after sweep to the fixpoint instead.  Both against the
+    oracle, on random many-layered columns (thin gaps, four materials: most pieces are small, some span the grid) and
+    through identify_cavity, whose flood runs on material 2."""
+    fem = _engine()
+    nx, ny, lm = 40, 56, 32
+    ln, mat, zp = _layered_columns(nx, ny, lm, layers, seed)
+    grids = []
+    for sweeps in (False, True):
+        if sweeps:
+            monkeypatch.setenv("CG_STRIP_SWEEPS", "1")
+        else:
+            monkeypatch.delenv("CG_STRIP_SWEEPS", raising=False)
+        g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+        g.upload(ln, mat, zp, lm)
+        g.strip_connected(4)
+        g.identify_cavity()
+        g.strip_connected(5)
+        grids.append(g)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    o.upload(ln, mat, zp, lm)
+    o.strip_connected(4); o.identify_cavity(); o.strip_connected(5)
+    oa = o.arrays()
+    _assert_same(grids[0], oa, "components")
+    _assert_same(grids[1], oa, "sweeps")
+    for g in grids:
+        g.close()
+
+
 def _layered_columns(nx, ny, lm, layers, seed):
     """Every column `layers` layers on a 5 nm pitch whose ends are pulled in by 0 .. 0.8 nm each (so most
     neighbouring layers are parted by a thin gap, at slightly different heights from column to column); one column

@@ -47,14 +47,14 @@ import re
 
 def parse(k):
     """-> (bench.py's group label, keeps statistics) of a step kernel, or None."""
-    if k.startswith("k_vertical_fused"):  # a run of vertical steps in one launch: never keeps statistics
+    if k.startswith("k_vertical_fused") or k.startswith("k_vertical_fresh"):  # a run of vertical steps in one launch: never keeps statistics
         return "k_vertical_fused", False
-    m = re.match(r"k_(stencil_stream|stencil_sym|stencil_apply|vertical_g4|vertical_1)<(.*)>", k)
+    m = re.match(r"k_(stencil_stream|stencil_lean|stencil_sym|stencil_apply|vertical_g4|vertical_1)<(.*)>", k)
     if not m:
         return None
     args = [a.strip() for a in m.group(2).split(",")]
     kind = m.group(1)
-    if kind == "stencil_stream":          # <R, ETCH, MSG, MASKED>: never keeps statistics
+    if kind in ("stencil_stream", "stencil_lean"):   # <R, ETCH, ...>: never keep statistics
         return "k_stencil<%s>" % ("etch" if args[1] == "true" else "deposit"), False
     if kind == "stencil_sym":             # <R, TJS, ETCH, STATS>
         return "k_stencil<%s>" % ("etch" if args[2] == "true" else "deposit"), args[3] == "true"
