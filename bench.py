@@ -21,6 +21,7 @@ Prints ONE JSON line (rank 0): metric = column updates per second, whole job.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -304,12 +305,27 @@ def main():
                 kd1 = kind_of(flow[run[0]])
                 kbytes[kd1] = kbytes.get(kd1, 0) + step_bytes[run[0]]
             run.clear()
+        # A lateral deposit of radius <= 4 on an undivided grid waits for the vertical steps behind it (up to FUSE_MAX - 1)
+        # and applies them inside its own launch (k_stencil_lean's FOLD form): their bytes then belong to that launch.
+        folding = fusing and world == 1 and not os.environ.get("CG_NO_FOLD")
+        fold_left, folded_steps, folded_launches, last_lateral = 0, 0, 0, -1
+        FOLDED = "k_stencil<deposit+vertical>"
         for q in range(total_steps):
             idx = (k + q) % len(flow)
             kd = kind_of(flow[idx])
             if idx == 0:
-                close_run()
+                close_run(); fold_left = 0
             if kd.startswith("k_vertical") and fusing:
+                if fold_left > 0 and not run:
+                    if fold_left == FUSE_MAX - 1:              # the first step behind the deposit: that launch is of the other kind
+                        folded_launches += 1
+                        kbytes["k_stencil<deposit>"] -= step_bytes[last_lateral]
+                        kbytes[FOLDED] = kbytes.get(FOLDED, 0) + step_bytes[last_lateral]
+                    kbytes[FOLDED] += step_bytes[idx]
+                    fold_left -= 1; folded_steps += 1
+                    if slice_idx:
+                        fold_left = 0
+                    continue
                 run.append(idx)
                 # (the run that starts on the reset grid goes out as one table look-up of up to 16 steps)
                 if len(run) == (16 if run[0] == 0 else FUSE_MAX) or slice_idx:
@@ -317,6 +333,10 @@ def main():
             else:
                 close_run()
                 kbytes[kd] = kbytes.get(kd, 0) + step_bytes[idx]
+                s_ = flow[idx]
+                lat = max(0.0, s_["t"]) * max(0.0, min(1.0, s_["S"]))
+                last_lateral = idx
+                fold_left = FUSE_MAX - 1 if (folding and kd == "k_stencil<deposit>" and math.ceil(lat / 2.0) <= 4 and not slice_idx) else 0
         close_run()
         kernels = {}
         for name, (ms, cnt) in prof.items():
@@ -326,7 +346,8 @@ def main():
                 kernels[name]["GBps"] = round(kbytes[name] / 1e9 / (ms / 1e3), 1)
         # the roofline object is about ONE step's kernel: a fused launch's algorithmic bytes are the sum of its steps', which
         # says how much traffic the fusion saved, not how close the launch runs to the memory rate
-        cand = {n_: v for n_, v in kernels.items() if "GBps" in v and n_ != "k_vertical_fused"}
+        MULTI = ("k_vertical_fused", FOLDED)          # groups whose launches apply several steps
+        cand = {n_: v for n_, v in kernels.items() if "GBps" in v and n_ not in MULTI}
         if not cand:                              # a flow of vertical steps only (C2): nothing but fused launches to report
             cand = {n_: v for n_, v in kernels.items() if "GBps" in v}
         dom = max(cand, key=lambda n_: cand[n_]["ms_total"]) if cand else None
@@ -358,7 +379,7 @@ def main():
         if dom:
             achieved = cand[dom]["GBps"]
             note = None
-            if dom == "k_vertical_fused":
+            if dom in MULTI:
                 # only fused launches ran (a flow of vertical steps): the sum of the fused steps' bytes over the launch time
                 # is not a memory rate (it passes the peak), so the rate given is the measured traffic's, or none
                 achieved = cand[dom].get("traffic_GBps")
@@ -390,6 +411,7 @@ def main():
             "whole_flow_algorithmic_GBps": round(total_alg * world / 1e9 / total_s, 1),
             "whole_flow_traffic_GBps": round(flow_traffic * world / 1e9 / total_s, 1) if flow_traffic else None,
             "fusion": {"vertical_steps_fused": fused_steps, "fused_launches": fused_launches,
+                       "vertical_steps_inside_lateral_deposits": folded_steps, "lateral_deposits_with_steps_inside": folded_launches,
                        "note": "runs of consecutive vertical steps are applied in one pass over the columns (k_vertical_fused); "
                                "its algorithmic bytes are the sum of its steps', so its GB/s is not an HBM rate; CG_NO_FUSE=1 launches every step on its own"},
             "checksum": "%016x" % check,

@@ -23,7 +23,7 @@ CG_NSTAT = 8
 CG_NKIND = 12
 KERNEL_KINDS = ["k_vertical_g4<deposit>", "k_vertical_g4<etch>", "k_vertical_fused", "k_halo_pack / k_ghost_pack",
                 "k_stencil<deposit>", "k_stencil<etch>", "k_mask_shapes", "clear(memset)",
-                "k_max_top", "other", "-", "-"]      # k_stencil = k_stencil_stream (k_stencil_sym / k_stencil_apply where it does not apply)
+                "k_max_top", "other", "k_stencil<deposit+vertical>", "-"]      # k_stencil = k_stencil_stream (k_stencil_sym / k_stencil_apply where it does not apply)
 STENCIL_DEPOSIT, STENCIL_ETCH = 0, 1
 SHAPE_RECT, SHAPE_CIRCLE, SHAPE_ELLIPSE, SHAPE_POLYGON, SHAPE_NEVER = range(5)
 

@@ -529,12 +529,33 @@ static __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hc
         // [q0, q1 - 32) if the range spans words and nothing if it does not.  United here are the bits really set.
         // (One range in 32 ends like that: in a wave of 64 columns nearly every tap has one, so sending them to
         // the bitset one by one made every lane wait through a marking pass per tap.)
-        int ua = 0, ub = 0; bool uhave = false;
+        // Three unions are kept at a time (an empty one has ub < ua): next to a step in the surface the taps bring
+        // ranges from the upper level and from the lower one in turn, and with one union every such turn sent a range
+        // to the bitset -- with 64 columns in a wave some lane did at nearly every tap, and all lanes waited.
+        constexpr int NU = 3;
+        int ua[NU], ub[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) { ua[u] = 0x7fffffff; ub[u] = -0x7fffffff - 1; }
         auto add_range = [&](int q0, int q1) {
             if ((q1 & 31) == 0) { q1 -= 32; if (q1 <= q0) return; }
-            if (uhave && q0 <= ub && q1 >= ua) { ua = min(ua, q0); ub = max(ub, q1); return; }
-            if (uhave) mark_range_exact(fill, ua, ub);
-            ua = q0; ub = q1; uhave = true;
+            bool placed = false;
+#pragma unroll
+            for (int u = 0; u < NU; u++) {                     // the first union it touches takes it in
+                const bool hit = !placed && q0 <= ub[u] && q1 >= ua[u];
+                ua[u] = hit ? min(ua[u], q0) : ua[u]; ub[u] = hit ? max(ub[u], q1) : ub[u];
+                placed |= hit;
+            }
+#pragma unroll
+            for (int u = 0; u < NU; u++) {                     // else the first empty place
+                const bool take = !placed && ub[u] < ua[u];
+                ua[u] = take ? q0 : ua[u]; ub[u] = take ? q1 : ub[u];
+                placed |= take;
+            }
+            if (placed) return;
+            mark_range_exact(fill, ua[0], ub[0]);              // else the oldest union goes to the bitset
+#pragma unroll
+            for (int u = 0; u + 1 < NU; u++) { ua[u] = ua[u + 1]; ub[u] = ub[u + 1]; }
+            ua[NU - 1] = q0; ub[NU - 1] = q1;
         };
         const bool in_box = inside && i >= imin && i <= imax && j >= jmin && j <= jmax;
         for (int tc = 0; tc < ntaps; tc += 64) {
@@ -608,7 +629,8 @@ static __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hc
             __builtin_amdgcn_wave_barrier();
         }
         if (!inside) continue;
-        if (uhave) mark_range_exact(fill, ua, ub);
+#pragma unroll
+        for (int u = 0; u < NU; u++) if (ub[u] > ua[u]) mark_range_exact(fill, ua[u], ub[u]);
         mark_occupied<true>(s, c, fill);                       // fill & ~occ, cg2:566-582
         fill.set(L.wpc - 1, fill.get(L.wpc - 1) & L.lastMask);
         insert_runs(s, d, c, fill, L.Zmax, mat, flags);

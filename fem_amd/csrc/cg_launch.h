@@ -10,7 +10,9 @@ struct StreamArgs {
     GridView gv; const uint8_t* mask; int mat; double t_eff; int Rimg;
     const uint8_t* halo_lo; const uint8_t* halo_up; const float* d_quad; StreamOpts so; int* flags; unsigned long long* stats;
     bool lean;      // every licence k_stencil_lean asks for holds (see cg_stencil_lean.hip.h): tiles that read no message take that form
+    const FusedOps* fold = nullptr;      // lean deposit of radius <= LEAN_FOLD_MAX_R: the vertical steps it takes along (op[0] stands for the deposit itself)
 };
+constexpr int LEAN_FOLD_MAX_R = 4;
 // k_stencil_stream<Re, etch, msg, masked> on `blocks` one-wave workgroups.  Re = 1..8 (larger: 8).
 void launch_stream(int Re, bool etch, bool msg, bool masked, unsigned blocks, hipStream_t stream, const StreamArgs& a);
 

@@ -10,9 +10,13 @@ namespace cgk {
 template <int RR>
 static void stream_one(bool etch, bool msg, bool masked, unsigned blocks, hipStream_t s, const StreamArgs& a) {
     if (a.lean && !msg) {
-#define LL(E, K) hipLaunchKernelGGL((k_stencil_lean<RR, E, K>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.d_quad, a.so)
-        if (etch) { if (masked) LL(true, true); else LL(true, false); }
-        else { if (masked) LL(false, true); else LL(false, false); }
+        static const FusedOps none = {};
+#define LL(E, K, F) hipLaunchKernelGGL((k_stencil_lean<RR, E, K, F>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.d_quad, a.so, a.fold ? *a.fold : none)
+        if constexpr (RR <= LEAN_FOLD_MAX_R) {
+            if (a.fold && !etch) { if (masked) LL(false, true, true); else LL(false, false, true); return; }
+        }
+        if (etch) { if (masked) LL(true, true, false); else LL(true, false, false); }
+        else { if (masked) LL(false, true, false); else LL(false, false, false); }
 #undef LL
         return;
     }

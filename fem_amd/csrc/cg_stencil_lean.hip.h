@@ -38,11 +38,15 @@ struct LeanRow { u32x4 a; uint32_t h; unsigned m, mh; };     // a staged row in 
 
 // Waves per SIMD the register allocation aims at.  Measured at 16384^2: R = 5 at 4 waves spills two registers inside the row
 // loop and is slower than at 3; the etch's update holds more values than the deposit's and spills at 5 waves already at R = 3.
-constexpr int lean_waves(int R, bool etch) { return R <= 3 ? (etch ? 4 : 5) : 3; }      // (the etch's update holds more: at 5 waves it spills)
+constexpr int lean_waves(int R, bool etch, bool fold) { return R <= 3 ? ((etch || fold) ? 4 : 5) : 3; }      // (the etch's update holds more: at 5 waves it spills)
 
-template <int R, bool ETCH, bool MASKED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R, ETCH)))) void k_stencil_lean(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
-                                                                                           const float* __restrict__ quad, const StreamOpts so) {
+// FOLD (deposits): the vertical steps that follow this one in the flow (F.op[1 .. F.n-1]; op[0] stands for this step, a
+// deposit into plane g.P) are applied to every output row right behind the step's own update, in registers, as
+// k_vertical_fused would apply them in a launch of its own: that launch's pass over the tops is saved.
+template <int R, bool ETCH, bool MASKED, bool FOLD = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R, ETCH, FOLD)))) void k_stencil_lean(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
+                                                                                           const float* __restrict__ quad, const StreamOpts so, const FusedOps F) {
+    static_assert(!(FOLD && ETCH), "only deposits take the following vertical steps along");
     using G = StreamGeom<R>;
     constexpr int Rp = G::Rp, PITCH = G::PITCH, W = G::W, TP = STREAM_TAB_PITCH;
     constexpr int RING = R + 1;         // the tops of staged rows r - R .. r: the slot of row r - R is read before row r + 1 takes it
@@ -170,6 +174,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
         const size_t orow = (size_t)(i_base + (FIN ? o : 0)) * (size_t)g.ny;                    // uniform
         unsigned mk = 0x01010101u;                         // deposit: the mask bytes of the output row (the etch keeps them in the ring)
         if (FIN && MASKED && !ETCH) mk = *(const unsigned*)(mask + orow + (m_off >> 2));
+        unsigned fopen[FUSE_MAX];                          // FOLD: the mask bytes of the steps taken along, for the output row
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int k = 0; k < FUSE_MAX; k++) {
+                fopen[k] = k < F.n ? 0x01010101u : 0u;
+                if (FIN && k >= 1 && k < F.n && F.masks[k]) fopen[k] = *(const unsigned*)(F.masks[k] + orow + (m_off >> 2));
+            }
+        }
         // ---- D[du] = op over dv of (p[dv] + a(du, dv)); row dv of the (symmetric) table lists the du's
         float D[R + 1][4];
 #pragma unroll
@@ -249,6 +261,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
                 nv[c] = on ? (same ? ext : app) : rc;
                 push |= (on & some & !same) ? (1u << c) : 0u;
             }
+            uint32_t pushed[FUSE_MAX][4];
+            if constexpr (FOLD) {
+                uint32_t r4[4] = {nv[0], nv[1], nv[2], nv[3]};
+#pragma unroll
+                for (int k = 0; k < FUSE_MAX; k++) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) pushed[k][c] = (k == 0 && ((push >> c) & 1)) ? tv[c] : 0u;
+                }
+                fused_steps<1>(g, F, orow + (m_off >> 2), fopen, r4, pushed);
+                nv[0] = r4[0]; nv[1] = r4[1]; nv[2] = r4[2]; nv[3] = r4[3];
+            }
             if (!m_right) {
                 if (push) {                                     // the old tops go into this step's plane as they are (see depo_group4)
                     uint32_t* pb = (uint32_t*)((char*)(g.rec + (size_t)g.P * g.N + orow) + m_off);
@@ -258,6 +281,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
                         for (int c = 0; c < 4; c++) if ((push >> c) & 1) pb[c] = tv[c];
                     }
                 }
+                if constexpr (FOLD) fused_store_planes<1>(g, F, orow + (m_off >> 2), pushed);
                 st_rec4((uint32_t*)((char*)(g.top_w + orow) + m_off), nv);
             }
         } else {

@@ -162,6 +162,10 @@ struct cg_grid {
     uint32_t* uf_list = nullptr; uint32_t* uf_counts = nullptr; size_t uf_segcap = 0;    // (inside uf) columns with an unmarked node, listed per seed block
     // vertical steps queued for one fused launch (see k_vertical_fused): nothing has looked at the grid since the first
     struct VQOp { const uint8_t* mask; bool etch; int mat; double t; int P; bool fresh; };
+    // A lateral deposit whose launch waits for the vertical steps that follow it (they go out inside its kernel, see
+    // k_stencil_lean's FOLD form).  Everything the host tracks is settled as if it had run, except the swap of the two
+    // top buffers, which follows the launch.
+    struct LatPending { bool active = false; const uint8_t* mask = nullptr; int mat = 0; double t_eff = 0; int R = 0; ConfKernel* K = nullptr; int P = -1; } lat;
     std::vector<VQOp> vq;
     bool fuse = true;                                      // CG_NO_FUSE=1: every vertical step is launched on its own
     struct VOptEntry { double t; bool etch; VertOpts vo; };
@@ -213,7 +217,7 @@ namespace {
          if (e__ != hipSuccess) return fail(g, CG_ERR_HIP, "hipSetDevice(%d): %s", (g)->device, hipGetErrorString(e__)); } while (0)
 // every entry point but the one that queues vertical steps first launches what is queued
 #define NEED_H(g)                                                                             \
-    do { NEED_H0(g); if (!(g)->vq.empty()) { int rcf__ = flush_vertical(g); if (rcf__) return rcf__; } } while (0)
+    do { NEED_H0(g); if (!(g)->vq.empty() || (g)->lat.active) { int rcf__ = flush_vertical(g); if (rcf__) return rcf__; } } while (0)
 // entry points that read or write the columns: a grid that was reset but whose streams have not
 // been cleared yet (see zero_planes) is cleared first
 #define NEED(g)                                                                               \
@@ -698,29 +702,40 @@ static unsigned sup_grid(GridView& gv, int t0, int tile_in, int tiles_j) {
     return (unsigned)(((n_s + 7) / 8) * 8 * gv.sup_i * gv.sup_j);
 }
 
-int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t_eff, int R, ConfKernel* K, int only_len,
-                   const uint8_t* halo_lo, const uint8_t* halo_up, int P, int part = PART_ALL, bool keep_len = false) {
+// The kernel families a lateral step can take: sym = the forms that leave the lengths behind, lean = the lean
+// row-streaming form (cg_stencil_lean.hip.h) for the tiles that read no message, streams = a row-streaming form at all.
+struct StencilForm { bool sym, lean, streams; };
+static StencilForm stencil_form(const cg_grid* g, const ConfKernel* K, bool etch, int mat, int only_len, bool keep_len) {
+    StencilForm f;
     // keep_len: a column may be full, so the lengths matter -> the general kernel, which reads and
     // maintains them; otherwise the symmetric kernel where it applies, which leaves them behind
-    const bool sym = g->split && only_len < 0 && !keep_len && K->sym_ok && g->ny % 4 == 0 && !getenv("CG_NO_SYM");
+    f.sym = g->split && only_len < 0 && !keep_len && K->sym_ok && g->ny % 4 == 0 && !getenv("CG_NO_SYM");
+    // The lean form when everything it takes for granted holds: the float licences, a centre increment well above the
+    // spacing of float32 heights (an open column then always grows), a material that an empty column's record cannot be
+    // mistaken for, 32-bit column indices.
+    static const bool no_lean = getenv("CG_NO_LEAN") != nullptr;
+    const float a00 = K->quad.empty() ? 0.f : K->quad[0];
+    f.lean = f.sym && !no_lean && g->sopt.deq_f32 && g->sopt.grow_f32 && !getenv("CG_STREAM_NOF32") && mat != 0 && a00 >= 0.01f &&
+             std::isfinite(a00) && g->N < ((size_t)1 << 31);
+    // Radii the streaming forms take: the lean deposit beats the gathering kernel at every radius (16384^2: R = 1 0.64 vs
+    // 0.67 ms, R = 2 0.66 vs 0.70); etches and the general streaming form from CG_STREAM_MINR (3) on.
+    const int min_r = (f.lean && !etch) ? std::min(1, stream_min_radius()) : stream_min_radius();
+    f.streams = f.sym && K->ntaps64_sym == 0 && K->Re >= min_r && !g->stats_on;
+    return f;
+}
+
+int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t_eff, int R, ConfKernel* K, int only_len,
+                   const uint8_t* halo_lo, const uint8_t* halo_up, int P, int part = PART_ALL, bool keep_len = false, const FusedOps* fold = nullptr) {
+    const StencilForm form = stencil_form(g, K, etch, mat, only_len, keep_len);
+    const bool sym = form.sym, lean = form.lean;
     if (!sym) { int rcl = ensure_len(g); if (rcl) return rcl; }
     GridView gv = view(g);
     gv.top_w = g->split ? g->top_alt : g->top; gv.P = P;      // (whole form: the planes are rewritten in place, top is only the copy of the old tops)
     const size_t lds = stencil_lds_bytes(R);
     const dim3 blk(256);
     Band bands[2];
-    ProfScope ps(g, etch ? CG_K_STENCIL_ETCH : CG_K_STENCIL_DEPOSIT);
-    // The lean row-streaming form (cg_stencil_lean.hip.h) takes the tiles that read no message when everything it takes for
-    // granted holds: the float licences, a centre increment well above the spacing of float32 heights (an open column then
-    // always grows), a material that an empty column's record cannot be mistaken for, 32-bit column indices.
-    static const bool no_lean = getenv("CG_NO_LEAN") != nullptr;
-    const float a00 = K->quad.empty() ? 0.f : K->quad[0];
-    const bool lean = sym && !no_lean && g->sopt.deq_f32 && g->sopt.grow_f32 && !getenv("CG_STREAM_NOF32") && mat != 0 && a00 >= 0.01f &&
-                      std::isfinite(a00) && g->N < ((size_t)1 << 31);
-    // Radii the streaming forms take: the lean deposit beats the gathering kernel at every radius (16384^2: R = 1 0.64 vs
-    // 0.67 ms, R = 2 0.66 vs 0.70); etches and the general streaming form from CG_STREAM_MINR (3) on.
-    const int min_r = (lean && !etch) ? std::min(1, stream_min_radius()) : stream_min_radius();
-    if (sym && K->ntaps64_sym == 0 && K->Re >= min_r && !g->stats_on) {
+    ProfScope ps(g, etch ? CG_K_STENCIL_ETCH : (fold ? CG_K_STENCIL_DEPOSIT_STEPS : CG_K_STENCIL_DEPOSIT));
+    if (form.streams) {
         // row-streaming form: one wave per tile of ti rows x STRIP columns
         g->len_valid = false;
         const int ti = stream_tile_rows();
@@ -735,7 +750,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
         if (getenv("CG_STREAM_NOF32")) { sopt.deq_f32 = 0; sopt.skip_init = 0; sopt.grow_f32 = 0; }
         sopt.a00 = K->quad.empty() ? 0.f : K->quad[0];
         sopt.fast_rows = (etch && !K->quad.empty() && K->quad[0] != -INFINITY && !getenv("CG_STREAM_NOFAST")) ? 1 : 0;
-        StreamArgs sa{gv, mask, mat, t_eff, R, halo_lo, halo_up, K->d_quad, sopt, g->d_flags, g->d_stats, lean};
+        StreamArgs sa{gv, mask, mat, t_eff, R, halo_lo, halo_up, K->d_quad, sopt, g->d_flags, g->d_stats, lean, fold};
         const auto go = [&](const Band& band, bool msg) {
             sa.gv.tile_i0 = band.t0; sa.gv.tile_in = band.n; sa.gv.sup_i = 1; sa.gv.sup_j = 1;
             launch_stream(K->Re, etch, msg, mask != nullptr, (unsigned)(((long)band.n * tiles_j + 7) / 8 * 8), g->stream, sa);
@@ -1101,6 +1116,30 @@ bool fresh_run(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, int* rc) {
 }
 
 int flush_vertical(cg_grid* g) {
+    if (g->lat.active) {
+        // the waiting lateral deposit, with the vertical steps queued behind it inside its launch when there are any
+        const cg_grid::LatPending L = g->lat;
+        g->lat.active = false;
+        std::vector<cg_grid::VQOp> behind; behind.swap(g->vq);
+        FusedOps F = {};
+        const bool fold = !behind.empty() && (int)behind.size() < FUSE_MAX;
+        if (fold) {
+            F.n = 1 + (int)behind.size();
+            F.op[0].etch = 0; F.op[0].mat = L.mat; F.op[0].P = L.P; F.op[0].t = L.t_eff; F.op[0].vo = VertOpts{-1, -1, -1, -1};
+            for (int k = 1; k < F.n; k++) {
+                const cg_grid::VQOp& o = behind[k - 1];
+                F.op[k].t = o.t; F.op[k].vo = vert_opts(g, o.t, o.etch);
+                F.op[k].etch = o.etch ? 1 : 0; F.op[k].mat = o.mat; F.op[k].P = o.P;
+                F.masks[k] = o.mask;
+            }
+            F.rt_shift = -1;
+        }
+        int rc = launch_stencil(g, false, L.mask, L.mat, L.t_eff, L.R, L.K, -1, nullptr, nullptr, L.P, 0 /* PART_ALL */, false, fold ? &F : nullptr);
+        if (rc) return rc;
+        std::swap(g->top, g->top_alt);
+        if (fold) return CG_OK;
+        g->vq.swap(behind);
+    }
     if (g->vq.empty()) return CG_OK;
     std::vector<cg_grid::VQOp> ops; ops.swap(g->vq);
     if (ops.size() == 1) {
@@ -1180,7 +1219,7 @@ int enqueue_vertical(cg_grid* g, bool etch, const uint8_t* mask, int mat, double
     g->len_valid = false;
     g->vq.push_back(op);
     // the run of a reset grid goes out as a table look-up whatever its length (fresh_run); any other run holds FUSE_MAX steps
-    const int cap = g->vq[0].fresh ? FRESH_MAX_STEPS : FUSE_MAX;
+    const int cap = g->vq[0].fresh ? FRESH_MAX_STEPS : (g->lat.active ? FUSE_MAX - 1 : FUSE_MAX);      // (a waiting lateral deposit takes the first place of its launch)
     if ((int)g->vq.size() >= cap) return flush_vertical(g);
     return CG_OK;
 }
@@ -1255,7 +1294,7 @@ int cg_create(double lx, double ly, double dx, double dy, int lmax_init, double 
 int cg_destroy(cg_grid* g) {
     if (!g) return CG_OK;
     (void)hipSetDevice(g->device);
-    g->vq.clear();
+    g->vq.clear(); g->lat.active = false;
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     free_planes(g);
     for (auto m : g->masks) if (m) (void)hipFree(m);
@@ -1286,7 +1325,7 @@ int cg_destroy(cg_grid* g) {
 
 int cg_reset(cg_grid* g, int lmax_init) {
     NEED_H0(g);
-    g->vq.clear();                       // queued vertical steps would be wiped out anyway: dropped, not launched
+    g->vq.clear(); g->lat.active = false;                       // queued vertical steps would be wiped out anyway: dropped, not launched
     int lmax = next_pow2(lmax_init > 0 ? lmax_init : g->lmax_vis);
     if (lmax > 256) lmax = 256;
     g->pend.active = false;
@@ -1310,7 +1349,7 @@ int cg_raise_lmax(cg_grid* g, int lmax) {
     return CG_OK;
 }
 
-int cg_clear(cg_grid* g) { NEED_H0(g); g->vq.clear(); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
+int cg_clear(cg_grid* g) { NEED_H0(g); g->vq.clear(); g->lat.active = false; g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
 
 int cg_get_info(const cg_grid* g, cg_info* o) {
     if (!g || !o) return CG_ERR_ARG;
@@ -1658,6 +1697,19 @@ int cg_stencil_finish(cg_grid* g) {
         return CG_OK;
     }
 
+    // A deposit that the lean kernel takes on an undivided grid waits for the vertical steps behind it: they go out
+    // inside its launch (flush_vertical).  Only when nothing of what the host tracks needs the device before that.
+    static const bool no_fold = getenv("CG_NO_FOLD") != nullptr;
+    if (!no_fold && g->fuse && !g->stats_on && g->split && part == PART_ALL && !halo_lo && !halo_up && !p.may_overflow && g->nx == g->nx_global &&
+        g->N % 4 == 0 && !g->has_gaps && !g->has_cavity && g->len_bound + 1 <= g->lmax_vis && p.K->Re <= LEAN_FOLD_MAX_R) {
+        const StencilForm form = stencil_form(g, p.K, false, p.mat, -1, false);
+        if (form.streams && form.lean) {
+            g->lat.active = true; g->lat.mask = mask; g->lat.mat = p.mat; g->lat.t_eff = p.t_eff; g->lat.R = p.R; g->lat.K = p.K; g->lat.P = p.P;
+            g->len_valid = false;
+            if (g->len_bound < 255) g->len_bound += 1;
+            return CG_OK;
+        }
+    }
     int rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, p.P, part, p.may_overflow); if (rc) return rc;
     if (p.may_overflow) {
         int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
@@ -2306,7 +2358,7 @@ int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
 int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8_t* len, int lmax) {
     NEED_H0(g);
     if (!mat || !zpair || !len || lmax < 1 || lmax > 256) return fail(g, CG_ERR_ARG, "bad upload arguments (lmax=%d)", lmax);
-    g->vq.clear();                       // every column is replaced: queued vertical steps are dropped, not launched
+    g->vq.clear(); g->lat.active = false;                       // every column is replaced: queued vertical steps are dropped, not launched
     g->pend.active = false;
     HIPCHK(g, hipStreamSynchronize(g->stream));
     if (lmax > g->lmax) { int rc = grow_planes(g, lmax - g->lmax); if (rc) return rc; }
@@ -2368,7 +2420,7 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     NEED_H0(g);
     auto it = g->snaps.find(slot);
     if (it == g->snaps.end()) return fail(g, CG_ERR_ARG, "no snapshot in slot %d", slot);
-    g->vq.clear();                       // the grid is replaced: queued vertical steps are dropped, not launched
+    g->vq.clear(); g->lat.active = false;                       // the grid is replaced: queued vertical steps are dropped, not launched
     const Snapshot& s = it->second;
     g->pend.active = false;
     if (s.planes > g->lmax) { int rc = grow_planes(g, (s.planes - g->lmax + 15) / 16 * 16); if (rc) return rc; }

@@ -240,3 +240,18 @@ def algorithmic_bytes(step_kind, stats):
     if step_kind in ("SUBSTR", "DEPO"):
         return 2 * (n - ext - app) + 7 * ext + 11 * app
     return 2 * (n - etched) + 9 * etched + 11 * removed + 3 * floor
+
+
+def wet_step_bytes(n_cols, layers_before, layers_after):
+    """Algorithmic bytes of one etch_wet increment (script_columngrid3.js:52-308), in the terms of algorithmic_bytes:
+    every column's stack is read once (1 B len + 5 B per layer: mat, z0/z1 as the reference stores them; what the
+    neighbours need of it is the same bytes again and counts as re-use) and the stack that comes out is written."""
+    return 2 * n_cols + 5 * (layers_before + layers_after)
+
+
+def ald_coat_bytes(n_cols, layers_before, layers_after, seeds):
+    """Algorithmic bytes of one coat of deposit_ALD (computeCoatBitsSingleT + applyCoatFromBits,
+    script_columngrid2.js:466-707): the stacks as in wet_step_bytes, plus every seed once (two u16 ends as the kernel
+    keeps them, 8 B with the padding of the reference's Float32 pair) and the 2-byte seed count of every column."""
+    return wet_step_bytes(n_cols, layers_before, layers_after) + 2 * n_cols + 8 * seeds
+

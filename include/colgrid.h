@@ -465,6 +465,7 @@ int cg_step_stats(cg_grid* g, int enable, uint64_t stats[CG_NSTAT]);
 #define CG_K_CLEAR           7   /* memsets of cg_reset / cg_clear                             */
 #define CG_K_REDUCE          8   /* k_max_top                                                  */
 #define CG_K_OTHER           9
+#define CG_K_STENCIL_DEPOSIT_STEPS 10 /* k_stencil_lean<deposit> with the vertical steps that follow it applied inside the launch */
 #define CG_NKIND 12
 int cg_profile(cg_grid* g, int enable, double ms[CG_NKIND], uint64_t count[CG_NKIND]);
 

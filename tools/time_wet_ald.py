@@ -17,10 +17,25 @@ for mat, t in ((3, 30), (4, 8), (5, 12)):
     g.deposit_general(None, mat, t, 0)
 g.etch_general(masks["M"], 255, 25, 0)
 g.sync()
-def timed(label, fn):
+lines = np.linspace(0, n - 1, 64).astype(np.int32)
+def layers():
+    """layers in the grid, from 64 lines of it"""
+    return float(g.slices("YZ", lines)[0].mean()) * n * n
+model = {"k_wet_step": [0, 0.0], "k_ald_coat": [0, 0.0]}       # launches, algorithmic bytes (fem_amd/flows.py)
+def timed(label, fn, kernel, launches):
+    lb = layers()
     g.sync(); t0 = time.time(); fn(); g.sync(); dt = time.time() - t0
-    print("%-34s %8.2f ms  %7.2f Gcol/s  Lmax %d  chk %016x" % (label, dt * 1e3, n * n / dt / 1e9, g.Lmax, g.checksum()))
-timed("etch_wet(Ox, 4)  [2 increments]", lambda: g.etch_wet(4, 4))
-timed("deposit_ALD(6, 4) [1 incr + final]", lambda: g.deposit_ALD(6, 4))
-timed("etch_wet(ALL, 2)  [1 increment]", lambda: g.etch_wet(255, 2))
-timed("deposit_ALD(7, 6) [2 incr + final]", lambda: g.deposit_ALD(7, 6))
+    la = layers()
+    # (the stacks of every launch of a call are taken as the mean of the call's first and last state)
+    if kernel == "k_wet_step":
+        b = flows.wet_step_bytes(n * n, (lb + la) / 2, (lb + la) / 2)
+    else:
+        b = flows.ald_coat_bytes(n * n, (lb + la) / 2, (lb + la) / 2, g.slider_sizes()[2])
+    model[kernel][0] += launches; model[kernel][1] += launches * b
+    print("%-34s %8.2f ms  %7.2f Gcol/s  Lmax %d  chk %016x  layers/column %.2f -> %.2f" % (label, dt * 1e3, n * n / dt / 1e9, g.Lmax, g.checksum(), lb / n / n, la / n / n))
+timed("etch_wet(Ox, 4)  [2 increments]", lambda: g.etch_wet(4, 4), "k_wet_step", 2)
+timed("deposit_ALD(6, 4) [1 incr + final]", lambda: g.deposit_ALD(6, 4), "k_ald_coat", 2)
+timed("etch_wet(ALL, 2)  [1 increment]", lambda: g.etch_wet(255, 2), "k_wet_step", 1)
+timed("deposit_ALD(7, 6) [2 incr + final]", lambda: g.deposit_ALD(7, 6), "k_ald_coat", 3)
+for k, (cnt, b) in model.items():
+    print("MODEL %s launches %d algorithmic_bytes %d" % (k, cnt, int(b)))
