@@ -308,7 +308,7 @@ def main():
         # A lateral deposit of radius <= 4 on an undivided grid waits for the vertical steps behind it (up to FUSE_MAX - 1)
         # and applies them inside its own launch (k_stencil_lean's FOLD form): their bytes then belong to that launch.
         folding = fusing and world == 1 and not os.environ.get("CG_NO_FOLD")
-        fold_left, folded_steps, folded_launches, last_lateral = 0, 0, 0, -1
+        fold_left, folded_steps, folded_launches, last_lateral, prefolded = 0, 0, 0, -1, False
         FOLDED = "k_stencil<deposit+vertical>"
         for q in range(total_steps):
             idx = (k + q) % len(flow)
@@ -317,10 +317,11 @@ def main():
                 close_run(); fold_left = 0
             if kd.startswith("k_vertical") and fusing:
                 if fold_left > 0 and not run:
-                    if fold_left == FUSE_MAX - 1:              # the first step behind the deposit: that launch is of the other kind
+                    if fold_left == FUSE_MAX - 1 and not prefolded:      # the first step behind the deposit: that launch is of the other kind
                         folded_launches += 1
                         kbytes["k_stencil<deposit>"] -= step_bytes[last_lateral]
                         kbytes[FOLDED] = kbytes.get(FOLDED, 0) + step_bytes[last_lateral]
+                    prefolded = False
                     kbytes[FOLDED] += step_bytes[idx]
                     fold_left -= 1; folded_steps += 1
                     if slice_idx:
@@ -331,10 +332,20 @@ def main():
                 if len(run) == (16 if run[0] == 0 else FUSE_MAX) or slice_idx:
                     close_run()
             else:
-                close_run()
-                kbytes[kd] = kbytes.get(kd, 0) + step_bytes[idx]
                 s_ = flow[idx]
                 lat = max(0.0, s_["t"]) * max(0.0, min(1.0, s_["S"]))
+                # the run waiting on the reset grid goes out inside a lateral deposit without a mask that follows it (FRESH form)
+                if folding and run and run[0] == 0 and kd == "k_stencil<deposit>" and s_["mask"] is None and not slice_idx:
+                    kbytes[FOLDED] = kbytes.get(FOLDED, 0) + sum(step_bytes[i] for i in run) + step_bytes[idx]
+                    folded_steps += len(run); folded_launches += 1
+                    run.clear()
+                    last_lateral = idx
+                    kbytes.setdefault("k_stencil<deposit>", 0)
+                    if math.ceil(lat / 2.0) <= 4:
+                        fold_left = FUSE_MAX - 1; prefolded = True
+                    continue
+                close_run()
+                kbytes[kd] = kbytes.get(kd, 0) + step_bytes[idx]
                 last_lateral = idx
                 fold_left = FUSE_MAX - 1 if (folding and kd == "k_stencil<deposit>" and math.ceil(lat / 2.0) <= 4 and not slice_idx) else 0
         close_run()

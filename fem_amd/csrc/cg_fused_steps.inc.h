@@ -114,13 +114,9 @@
         const bool p0 = pushed[k][0] != 0, p1 = pushed[k][1] != 0, p2 = pushed[k][2] != 0, p3 = pushed[k][3] != 0;
         if (!(p0 || p1 || p2 || p3)) continue;
         const size_t at = (size_t)F.op[k].P * g.N + c0;
-        if (p0 && p1 && p2 && p3) { u32x4 v; v[0] = pushed[k][0]; v[1] = pushed[k][1]; v[2] = pushed[k][2]; v[3] = pushed[k][3]; st_rec4(g.rec + at, v); }
-        else {
-            if (p0) g.rec[at] = pushed[k][0];
-            if (p1) g.rec[at + 1] = pushed[k][1];
-            if (p2) g.rec[at + 2] = pushed[k][2];
-            if (p3) g.rec[at + 3] = pushed[k][3];
-        }
+        // (the plane is this deposit's own and a slot of it that no chain names may hold anything: the group goes out in
+        // one store, zeros where a column pushed nothing)
+        { u32x4 v; v[0] = pushed[k][0]; v[1] = pushed[k][1]; v[2] = pushed[k][2]; v[3] = pushed[k][3]; st_rec4(g.rec + at, v); }
     }
 
 #endif

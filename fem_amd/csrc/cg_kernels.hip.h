@@ -775,11 +775,9 @@ __global__ __launch_bounds__(256) void k_vertical_fresh(GridView g, const FreshT
 #pragma unroll
             for (int j = 0; j < 4; j++) pv[j] = s_tab[(1 + d) * NC + cls[j]];
             uint32_t* at = g.rec + (size_t)T.plane[d] * g.N + c0;
-            if (pv[0] && pv[1] && pv[2] && pv[3]) st_rec4(at, pv);
-            else {
-#pragma unroll
-                for (int j = 0; j < 4; j++) if (pv[j]) at[j] = pv[j];
-            }
+            // (a slot of the deposit's own plane that no chain names may hold anything: one store for the group when any
+            // of its columns pushed, zeros for the others)
+            if (pv[0] | pv[1] | pv[2] | pv[3]) st_rec4(at, pv);
         }
     }
 }
@@ -1319,7 +1317,8 @@ __device__ __forceinline__ RawCol stream_load1(const GridView& g, const uint8_t*
 //              reference's 1e-9: "Hp - H > 1e-9" (cg1:537) is then "Hp > H" on the float32 values
 //   a00        the centre increment of the table (a float32-exact tap, or this kernel is not used)
 //   fast_rows  etch: the rows of a tile are first tried without their neighbours (stream_etch_fast_rows)
-struct StreamOpts { float zs_hi, zs_lo, izf; int deq_f32, skip_init, grow_f32; float a00; int fast_rows; };
+// sink: 4 MiB nobody reads, for stores that must be issued but have nothing to say (see k_stencil_lean's deposit update).
+struct StreamOpts { float zs_hi, zs_lo, izf; int deq_f32, skip_init, grow_f32; float a00; int fast_rows; uint32_t* sink; };
 
 __device__ __forceinline__ float stream_deq(const GridView& g, const StreamOpts& o, unsigned q) {
     if (o.deq_f32) { const float qf = (float)q; return __builtin_fmaf(qf, o.zs_hi, qf * o.zs_lo); }

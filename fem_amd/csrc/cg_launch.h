@@ -11,6 +11,7 @@ struct StreamArgs {
     const uint8_t* halo_lo; const uint8_t* halo_up; const float* d_quad; StreamOpts so; int* flags; unsigned long long* stats;
     bool lean;      // every licence k_stencil_lean asks for holds (see cg_stencil_lean.hip.h): tiles that read no message take that form
     const FusedOps* fold = nullptr;      // lean deposit of radius <= LEAN_FOLD_MAX_R: the vertical steps it takes along (op[0] stands for the deposit itself)
+    const FreshTab* fresh = nullptr;     // lean deposit without a mask: the run of vertical steps on the reset grid in front of it (FRESH form)
 };
 constexpr int LEAN_FOLD_MAX_R = 4;
 // k_stencil_stream<Re, etch, msg, masked> on `blocks` one-wave workgroups.  Re = 1..8 (larger: 8).

@@ -11,12 +11,18 @@ template <int RR>
 static void stream_one(bool etch, bool msg, bool masked, unsigned blocks, hipStream_t s, const StreamArgs& a) {
     if (a.lean && !msg) {
         static const FusedOps none = {};
-#define LL(E, K, F) hipLaunchKernelGGL((k_stencil_lean<RR, E, K, F>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.d_quad, a.so, a.fold ? *a.fold : none)
-        if constexpr (RR <= LEAN_FOLD_MAX_R) {
-            if (a.fold && !etch) { if (masked) LL(false, true, true); else LL(false, false, true); return; }
+        static const FreshTab no_run = {};
+#define LL(E, K, F, W) hipLaunchKernelGGL((k_stencil_lean<RR, E, K, F, W>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.d_quad, a.so, \
+                                          a.fold ? *a.fold : none, a.fresh ? *a.fresh : no_run)
+        if (a.fresh && !etch && !masked) {                  // (the host asks for this form only where it exists)
+            if constexpr (RR <= LEAN_FOLD_MAX_R) { if (a.fold) { LL(false, false, true, true); return; } }
+            LL(false, false, false, true); return;
         }
-        if (etch) { if (masked) LL(true, true, false); else LL(true, false, false); }
-        else { if (masked) LL(false, true, false); else LL(false, false, false); }
+        if constexpr (RR <= LEAN_FOLD_MAX_R) {
+            if (a.fold && !etch) { if (masked) LL(false, true, true, false); else LL(false, false, true, false); return; }
+        }
+        if (etch) { if (masked) LL(true, true, false, false); else LL(true, false, false, false); }
+        else { if (masked) LL(false, true, false, false); else LL(false, false, false, false); }
 #undef LL
         return;
     }

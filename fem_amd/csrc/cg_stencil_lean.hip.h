@@ -35,6 +35,7 @@ __device__ __forceinline__ bool lean_quant(const StreamOpts& o, float h, unsigne
 }
 
 struct LeanRow { u32x4 a; uint32_t h; unsigned m, mh; };     // a staged row in flight: 4 tops, one halo column's top, their mask bytes
+struct LeanFresh { unsigned m[FRESH_MAX_MASKS], h[FRESH_MAX_MASKS]; };      // FRESH: the bytes of the run's masks at those columns instead of tops
 
 // Waves per SIMD the register allocation aims at.  Measured at 16384^2: R = 5 at 4 waves spills two registers inside the row
 // loop and is slower than at 3; the etch's update holds more values than the deposit's and spills at 5 waves already at R = 3.
@@ -43,10 +44,17 @@ constexpr int lean_waves(int R, bool etch, bool fold) { return R <= 3 ? ((etch |
 // FOLD (deposits): the vertical steps that follow this one in the flow (F.op[1 .. F.n-1]; op[0] stands for this step, a
 // deposit into plane g.P) are applied to every output row right behind the step's own update, in registers, as
 // k_vertical_fused would apply them in a launch of its own: that launch's pass over the tops is saved.
-template <int R, bool ETCH, bool MASKED, bool FOLD = false>
+// FRESH (deposits): the grid has just been reset and a run of vertical steps is waiting in front of this step.  The top
+// of a column after that run is one of 2^masks records (FreshTab, see k_vertical_fresh): every row this tile reads is
+// put together from the run's mask bytes instead of being loaded, and the tile stores what the run's deposits pushed for
+// the rows it owns -- the run never gets a launch of its own, and its tops are never written or read.
+template <int R, bool ETCH, bool MASKED, bool FOLD = false, bool FRESH = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R, ETCH, FOLD)))) void k_stencil_lean(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
-                                                                                           const float* __restrict__ quad, const StreamOpts so, const FusedOps F) {
-    static_assert(!(FOLD && ETCH), "only deposits take the following vertical steps along");
+                                                                                           const float* __restrict__ quad, const StreamOpts so, const FusedOps F, const FreshTab T) {
+    static_assert(!((FOLD || FRESH) && ETCH), "only deposits take vertical steps along");
+    constexpr int NC = 1 << FRESH_MAX_MASKS;
+    __shared__ uint32_t s_ftab[FRESH ? (1 + FRESH_MAX_DEP) * NC : 1];       // [0..NC) tops per class, then NC entries per deposit of the run
+    __shared__ unsigned s_cls[FRESH ? R + 1 : 1][64];                          // the classes of the 4 columns of a staged row (3 bits each)
     using G = StreamGeom<R>;
     constexpr int Rp = G::Rp, PITCH = G::PITCH, W = G::W, TP = STREAM_TAB_PITCH;
     constexpr int RING = R + 1;         // the tops of staged rows r - R .. r: the slot of row r - R is read before row r + 1 takes it
@@ -65,6 +73,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
     for (int e = lane; e < (R + 1) * TP; e += 64) {
         const int dv = e / TP, du = e - dv * TP;
         s_tab[e] = du <= R ? quad[dv * (R + 1) + du] : -__builtin_inff();
+    }
+    if (FRESH) {
+        for (int e = lane; e < (1 + T.ndep) * NC; e += 64) s_ftab[e] = e < NC ? T.top[e] : T.pushed[e / NC - 1][e % NC];
+        __builtin_amdgcn_s_barrier();
     }
     const bool m_right = j0 >= g.ny;                       // lanes beyond the last column repeat the edge group; only their stores are left out
     const unsigned m_off = 4u * (unsigned)(m_right ? g.ny - 4 : j0);          // byte offset of the lane's group inside a row of tops
@@ -87,13 +99,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
     const int last_row = g.nx - 1;
 
     // input row `il` (any integer; rows beyond the slab repeat its edge row with every flag clear, cg1:381-387, 671)
+    LeanFresh wf;                                          // (FRESH) filled by load_row next to the row it returns, looked at by stage
     const auto load_row = [&](int il) __attribute__((always_inline)) {
         LeanRow w;
         const bool edge = il < 0 || il > last_row;
         const int ic = il < 0 ? 0 : (il > last_row ? last_row : il);
         const char* rowp = (const char*)g.top + (size_t)ic * row_bytes;                        // uniform
-        w.a = *(const u32x4*)(rowp + m_off);
-        w.h = *(const uint32_t*)(rowp + h_off);
+        if (!FRESH) {
+            w.a = *(const u32x4*)(rowp + m_off);
+            w.h = *(const uint32_t*)(rowp + h_off);
+        } else {
+            w.a = (u32x4)(0); w.h = 0;
+#pragma unroll
+            for (int q = 0; q < FRESH_MAX_MASKS; q++) {
+                wf.m[q] = 0; wf.h[q] = 0;
+                if (q < T.nmask) {
+                    const uint8_t* mrow = T.mask[q] + (size_t)ic * (size_t)g.ny;               // uniform
+                    wf.m[q] = *(const unsigned*)(mrow + (m_off >> 2));
+                    wf.h[q] = mrow[h_off >> 2];
+                }
+            }
+        }
         w.m = 0x01010101u; w.mh = 1u;
         if (ETCH) {
             if (MASKED) {
@@ -106,7 +132,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
         return w;
     };
     // float32 heights of a loaded row into s_row[slot]; its tops (etch: and mask bytes) into ring slot `rs`
-    const auto stage = [&](const LeanRow& w, int slot, int rs) __attribute__((always_inline)) {
+    const auto stage = [&](const LeanRow& w_in, int slot, int rs) __attribute__((always_inline)) {
+        LeanRow w = w_in;
+        if (FRESH) {
+            unsigned cl[4] = {0, 0, 0, 0}, clh = 0;
+#pragma unroll
+            for (int q = 0; q < FRESH_MAX_MASKS; q++) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) cl[c] |= ((wf.m[q] >> (8 * c)) & 0xffu) ? (1u << q) : 0u;
+                clh |= wf.h[q] ? (1u << q) : 0u;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) w.a[c] = s_ftab[cl[c]];
+            w.h = s_ftab[clh];
+            s_cls[rs][lane] = cl[0] | (cl[1] << 3) | (cl[2] << 6) | (cl[3] << 9);
+        }
         float4 h;
         unsigned q[4];
 #pragma unroll
@@ -215,13 +255,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
         for (int k = 0; k <= 2 * R; k++) { asm volatile("" : "+v"(A[k][0]), "+v"(A[k][1]), "+v"(A[k][2]), "+v"(A[k][3])); }
         // ---- the output row's records, from the ring (read before row r + 1 takes their slot)
         u32x4 tv = (u32x4)(0);
+        unsigned fcl = 0;                                  // FRESH: the classes of the output row's columns
         if (FIN) {
             tv = *(const u32x4*)(s_top[ring_o] + 4 * lane);
             if (ETCH) mk = s_msk[ring_o][lane];
+            if (FRESH) fcl = s_cls[ring_o][lane];
         }
         // ---- stage input row r + 1, start the loads of row r + 2
         // (the loaded row is looked at from here on: the compiler otherwise starts on it right behind its load, and waits there)
-        asm volatile("" : "+v"(in.a[0]), "+v"(in.a[1]), "+v"(in.a[2]), "+v"(in.a[3]), "+v"(in.h), "+v"(in.m), "+v"(in.mh));
+        if (!FRESH) asm volatile("" : "+v"(in.a[0]), "+v"(in.a[1]), "+v"(in.a[2]), "+v"(in.a[3]), "+v"(in.h), "+v"(in.m), "+v"(in.mh));
+        else asm volatile("" : "+v"(wf.m[0]), "+v"(wf.m[1]), "+v"(wf.m[2]), "+v"(wf.h[0]), "+v"(wf.h[1]), "+v"(wf.h[2]));
         stage(in, (r + 1) & 1, ring_w);
         ring_w = ring_w + 1 >= RING ? 0 : ring_w + 1;
         in = load_row(i_base - R + r + 2);
@@ -272,17 +315,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
                 fused_steps<1>(g, F, orow + (m_off >> 2), fopen, r4, pushed);
                 nv[0] = r4[0]; nv[1] = r4[1]; nv[2] = r4[2]; nv[3] = r4[3];
             }
+            {
+                // Exactly two full stores per row and lane, whatever the columns do (no branches, no single-record
+                // stores next to a material boundary).  The old tops go into this step's plane when any column of the wave
+                // pushes (a slot no chain names may hold anything); a wave without a push, and the lanes that repeat the
+                // edge group, store into the sink, which stays in the cache.  Measured at 16384^2, R = 5 where half the
+                // columns extend their top layer: 0.78 -> 0.72 ms.
+                const bool anyp = __ballot(push != 0) != 0ull;
+                char* sink = (char*)so.sink + ((blockIdx.x & 4095u) << 10) + 16 * lane;
+                char* pb = (char*)(g.rec + (size_t)g.P * g.N + orow) + m_off;
+                st_rec4((uint32_t*)((anyp && !m_right) ? pb : sink), tv);
+                st_rec4((uint32_t*)(m_right ? sink : (char*)(g.top_w + orow) + m_off), nv);
+            }
             if (!m_right) {
-                if (push) {                                     // the old tops go into this step's plane as they are (see depo_group4)
-                    uint32_t* pb = (uint32_t*)((char*)(g.rec + (size_t)g.P * g.N + orow) + m_off);
-                    if (push == 15u) st_rec4(pb, tv);
-                    else {
+                if constexpr (FOLD) fused_store_planes<1>(g, F, orow + (m_off >> 2), pushed);
+                if constexpr (FRESH) {                          // what the deposits of the run in front pushed (as k_vertical_fresh stores it)
+                    for (int d = 0; d < T.ndep; d++) {
+                        u32x4 pv;
 #pragma unroll
-                        for (int c = 0; c < 4; c++) if ((push >> c) & 1) pb[c] = tv[c];
+                        for (int c = 0; c < 4; c++) pv[c] = s_ftab[(1 + d) * NC + ((fcl >> (3 * c)) & 7u)];
+                        uint32_t* at = (uint32_t*)((char*)(g.rec + (size_t)T.plane[d] * g.N + orow) + m_off);
+                        if (__ballot((pv[0] | pv[1] | pv[2] | pv[3]) != 0) != 0ull) st_rec4(at, pv);      // (whole waves: zeros where nothing was pushed)
                     }
                 }
-                if constexpr (FOLD) fused_store_planes<1>(g, F, orow + (m_off >> 2), pushed);
-                st_rec4((uint32_t*)((char*)(g.top_w + orow) + m_off), nv);
             }
         } else {
             // _applyEtchAt (cg1:553-589) by dz = H - Hp (cg1:730-739) on the open, etchable columns (act0, worked out when

@@ -92,6 +92,7 @@ struct Snapshot {
 };
 
 struct Pending {
+    bool prefold = false;       // the queue of vertical steps on the reset grid was left waiting for this deposit (see cg_stencil_begin)
     bool active = false;
     int kind = 0, mask_id = CG_MASK_NONE, mat = 0, R = 0;
     double t_eff = 0;
@@ -156,6 +157,7 @@ struct cg_grid {
     // planes are seed_stride entries apart (a whole grid: seed_off = 0, seed_stride = N, no neighbour rows)
     size_t seed_stride = 0, seed_off = 0; int seed_rows = 0; bool seed_lo = false, seed_hi = false;
     int* d_bbox = nullptr;
+    uint32_t* d_sink = nullptr;                            // 4 MiB that nobody reads (StreamOpts::sink)
     uint8_t* cand = nullptr;                               // strip_connected: columns that still hold an unmarked node
     uint32_t* uf = nullptr; size_t uf_cap = 0;             // strip_connected: the union-find forest over the nodes (uf_cap words), kept until cg_release_scratch
     bool uf_on = false, uf_joined = false;                 // this flood runs on the forest / the forest has been joined
@@ -165,7 +167,10 @@ struct cg_grid {
     // A lateral deposit whose launch waits for the vertical steps that follow it (they go out inside its kernel, see
     // k_stencil_lean's FOLD form).  Everything the host tracks is settled as if it had run, except the swap of the two
     // top buffers, which follows the launch.
-    struct LatPending { bool active = false; const uint8_t* mask = nullptr; int mat = 0; double t_eff = 0; int R = 0; ConfKernel* K = nullptr; int P = -1; } lat;
+    // pre: the run of vertical steps that was waiting on the reset grid when the deposit came (applied in the same launch,
+    // k_stencil_lean's FRESH form).
+    struct LatPending { bool active = false; const uint8_t* mask = nullptr; int mat = 0; double t_eff = 0; int R = 0; ConfKernel* K = nullptr; int P = -1;
+                        std::vector<VQOp> pre; } lat;
     std::vector<VQOp> vq;
     bool fuse = true;                                      // CG_NO_FUSE=1: every vertical step is launched on its own
     struct VOptEntry { double t; bool etch; VertOpts vo; };
@@ -725,7 +730,8 @@ static StencilForm stencil_form(const cg_grid* g, const ConfKernel* K, bool etch
 }
 
 int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t_eff, int R, ConfKernel* K, int only_len,
-                   const uint8_t* halo_lo, const uint8_t* halo_up, int P, int part = PART_ALL, bool keep_len = false, const FusedOps* fold = nullptr) {
+                   const uint8_t* halo_lo, const uint8_t* halo_up, int P, int part = PART_ALL, bool keep_len = false, const FusedOps* fold = nullptr,
+                   const FreshTab* fresh = nullptr) {
     const StencilForm form = stencil_form(g, K, etch, mat, only_len, keep_len);
     const bool sym = form.sym, lean = form.lean;
     if (!sym) { int rcl = ensure_len(g); if (rcl) return rcl; }
@@ -734,7 +740,7 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
     const size_t lds = stencil_lds_bytes(R);
     const dim3 blk(256);
     Band bands[2];
-    ProfScope ps(g, etch ? CG_K_STENCIL_ETCH : (fold ? CG_K_STENCIL_DEPOSIT_STEPS : CG_K_STENCIL_DEPOSIT));
+    ProfScope ps(g, etch ? CG_K_STENCIL_ETCH : ((fold || fresh) ? CG_K_STENCIL_DEPOSIT_STEPS : CG_K_STENCIL_DEPOSIT));
     if (form.streams) {
         // row-streaming form: one wave per tile of ti rows x STRIP columns
         g->len_valid = false;
@@ -749,8 +755,10 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
         sopt.skip_init = ((double)(float)t_eff == t_eff && !K->quad.empty() && K->quad[0] == (float)t_eff) ? 1 : 0;
         if (getenv("CG_STREAM_NOF32")) { sopt.deq_f32 = 0; sopt.skip_init = 0; sopt.grow_f32 = 0; }
         sopt.a00 = K->quad.empty() ? 0.f : K->quad[0];
+        if (!g->d_sink) HIPCHK(g, hipMalloc(&g->d_sink, (size_t)4 << 20));
+        sopt.sink = g->d_sink;
         sopt.fast_rows = (etch && !K->quad.empty() && K->quad[0] != -INFINITY && !getenv("CG_STREAM_NOFAST")) ? 1 : 0;
-        StreamArgs sa{gv, mask, mat, t_eff, R, halo_lo, halo_up, K->d_quad, sopt, g->d_flags, g->d_stats, lean, fold};
+        StreamArgs sa{gv, mask, mat, t_eff, R, halo_lo, halo_up, K->d_quad, sopt, g->d_flags, g->d_stats, lean, fold, fresh};
         const auto go = [&](const Band& band, bool msg) {
             sa.gv.tile_i0 = band.t0; sa.gv.tile_in = band.n; sa.gv.sup_i = 1; sa.gv.sup_j = 1;
             launch_stream(K->Re, etch, msg, mask != nullptr, (unsigned)(((long)band.n * tiles_j + 7) / 8 * 8), g->stream, sa);
@@ -1067,11 +1075,10 @@ struct HostColumn {
 
 // The run `ops` starts on a reset grid.  When it has at most FRESH_MAX_MASKS distinct masks its outcome per column is one
 // of 2^masks columns worked out here; k_vertical_fresh stores them.  Returns false when the run does not qualify.
-bool fresh_run(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, int* rc) {
+bool fresh_table(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, FreshTab& T) {
     static const bool off = getenv("CG_NO_FRESH_RUN") != nullptr;
-    *rc = CG_OK;
     if (off || ops.empty() || !ops[0].fresh || (int)ops.size() > FRESH_MAX_STEPS || g->N % 4 != 0) return false;
-    FreshTab T = {};
+    T = FreshTab{};
     std::vector<int> mask_of(ops.size(), -1);
     for (size_t k = 0; k < ops.size(); k++) {
         if (!ops[k].mask) continue;
@@ -1101,6 +1108,13 @@ bool fresh_run(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, int* rc) {
         }
     }
     T.rt_shift = -1;
+    return true;
+}
+
+bool fresh_run(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, int* rc) {
+    *rc = CG_OK;
+    FreshTab T;
+    if (!fresh_table(g, ops, T)) return false;
     const size_t nb = (g->N / 4 + (size_t)256 * FRESH_U - 1) / ((size_t)256 * FRESH_U);
     ProfScope ps(g, CG_K_VERTICAL_FUSED);
     const dim3 grid((unsigned)std::max<size_t>(1, nb));
@@ -1119,10 +1133,10 @@ int flush_vertical(cg_grid* g) {
     if (g->lat.active) {
         // the waiting lateral deposit, with the vertical steps queued behind it inside its launch when there are any
         const cg_grid::LatPending L = g->lat;
-        g->lat.active = false;
+        g->lat.active = false; g->lat.pre.clear();
         std::vector<cg_grid::VQOp> behind; behind.swap(g->vq);
         FusedOps F = {};
-        const bool fold = !behind.empty() && (int)behind.size() < FUSE_MAX;
+        const bool fold = !behind.empty() && (int)behind.size() < FUSE_MAX && L.K->Re <= LEAN_FOLD_MAX_R;
         if (fold) {
             F.n = 1 + (int)behind.size();
             F.op[0].etch = 0; F.op[0].mat = L.mat; F.op[0].P = L.P; F.op[0].t = L.t_eff; F.op[0].vo = VertOpts{-1, -1, -1, -1};
@@ -1134,7 +1148,10 @@ int flush_vertical(cg_grid* g) {
             }
             F.rt_shift = -1;
         }
-        int rc = launch_stencil(g, false, L.mask, L.mat, L.t_eff, L.R, L.K, -1, nullptr, nullptr, L.P, 0 /* PART_ALL */, false, fold ? &F : nullptr);
+        FreshTab T;
+        const bool pre = !L.pre.empty();
+        if (pre && !fresh_table(g, L.pre, T)) return fail(g, CG_ERR_STATE, "the waiting run of vertical steps no longer fits the table form");
+        int rc = launch_stencil(g, false, L.mask, L.mat, L.t_eff, L.R, L.K, -1, nullptr, nullptr, L.P, 0 /* PART_ALL */, false, fold ? &F : nullptr, pre ? &T : nullptr);
         if (rc) return rc;
         std::swap(g->top, g->top_alt);
         if (fold) return CG_OK;
@@ -1294,7 +1311,7 @@ int cg_create(double lx, double ly, double dx, double dy, int lmax_init, double 
 int cg_destroy(cg_grid* g) {
     if (!g) return CG_OK;
     (void)hipSetDevice(g->device);
-    g->vq.clear(); g->lat.active = false;
+    g->vq.clear(); g->lat.active = false; g->lat.pre.clear();
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     free_planes(g);
     for (auto m : g->masks) if (m) (void)hipFree(m);
@@ -1308,6 +1325,7 @@ int cg_destroy(cg_grid* g) {
     if (g->d_sum) (void)hipFree(g->d_sum);
     if (g->d_bbox) (void)hipFree(g->d_bbox);
     if (g->cand) (void)hipFree(g->cand);
+    if (g->d_sink) (void)hipFree(g->d_sink);
     if (g->uf) (void)hipFree(g->uf);
     if (g->d_ald_taps) (void)hipFree(g->d_ald_taps);
     free_alt(g, 0); free_alt(g, 1); drop_seeds(g);
@@ -1325,7 +1343,7 @@ int cg_destroy(cg_grid* g) {
 
 int cg_reset(cg_grid* g, int lmax_init) {
     NEED_H0(g);
-    g->vq.clear(); g->lat.active = false;                       // queued vertical steps would be wiped out anyway: dropped, not launched
+    g->vq.clear(); g->lat.active = false; g->lat.pre.clear();                       // queued vertical steps would be wiped out anyway: dropped, not launched
     int lmax = next_pow2(lmax_init > 0 ? lmax_init : g->lmax_vis);
     if (lmax > 256) lmax = 256;
     g->pend.active = false;
@@ -1349,7 +1367,7 @@ int cg_raise_lmax(cg_grid* g, int lmax) {
     return CG_OK;
 }
 
-int cg_clear(cg_grid* g) { NEED_H0(g); g->vq.clear(); g->lat.active = false; g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
+int cg_clear(cg_grid* g) { NEED_H0(g); g->vq.clear(); g->lat.active = false; g->lat.pre.clear(); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
 
 int cg_get_info(const cg_grid* g, cg_info* o) {
     if (!g || !o) return CG_ERR_ARG;
@@ -1532,7 +1550,14 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     // a vertical step joins the queue of vertical steps when the fused kernel can take it; anything else first
     // launches what is queued
     const bool can_fuse = latRange < std::min(g->dx, g->dy) && g->fuse && !g->stats_on && g->N % 4 == 0;
-    if (!can_fuse) { int rcf = flush_vertical(g); if (rcf) return rcf; }
+    // A lateral deposit without a mask that finds a run of vertical steps waiting on the reset grid leaves it waiting:
+    // when the deposit takes the lean kernel (known further down) the run goes out inside that launch.
+    static const bool no_fold = getenv("CG_NO_FOLD") != nullptr;
+    bool prefold = !no_fold && !can_fuse && kind == CG_STENCIL_DEPOSIT && !mask && !has_lower && !has_upper && g->nx == g->nx_global && g->fuse &&
+                   !g->stats_on && !g->lat.active && !g->vq.empty() && g->vq[0].fresh && g->split && !g->has_gaps && !g->has_cavity &&
+                   g->len_bound + 1 <= g->lmax_vis && g->len_bound < g->lmax && g->nextp < std::min(g->lmax, SPLIT_PLANES);
+    if (prefold) { FreshTab probe; prefold = fresh_table(g, g->vq, probe); }
+    if (!can_fuse && !prefold) { int rcf = flush_vertical(g); if (rcf) return rcf; }
     // a reset grid whose first step is a deposit everywhere needs no clearing pass: the kernel writes
     // top of every column itself
     const bool fresh = g->pristine && kind == CG_STENCIL_DEPOSIT && latRange < std::min(g->dx, g->dy) && !mask && g->N % 4 == 0 && g->lmax >= 1;
@@ -1560,6 +1585,10 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     }
     ConfKernel* K = get_kernel(g, t, S);
     const int R = K->Rx;
+    if (prefold) {
+        const StencilForm form = stencil_form(g, K, false, mat, -1, false);
+        if (!(form.streams && form.lean)) { prefold = false; int rcf = flush_vertical(g); if (rcf) return rcf; }
+    }
     // The reference pads its height map by Rx cells in BOTH directions (script_columngrid.js:471, 666) while the taps reach
     // Ry = ceil(t/dy) cells along j.  With Ry <= Rx (any dy >= dx) every tap stays inside the pad and the step is well
     // defined; with Ry > Rx its reads run into the neighbouring pad row or past the end of a scratch buffer that keeps
@@ -1596,7 +1625,7 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     g->pend.active = true; g->pend.kind = kind; g->pend.mask_id = mask_id; g->pend.mat = mat; g->pend.R = R; g->pend.K = K;
     g->pend.t_eff = (kind == CG_STENCIL_DEPOSIT) ? K->baseAdd : t;        // cg1:470/499 vs cg1:702
     g->pend.has_lower = has_lower != 0; g->pend.has_upper = has_upper != 0;
-    g->pend.interior_done = false; g->pend.may_overflow = false; g->pend.P = -1;
+    g->pend.interior_done = false; g->pend.may_overflow = false; g->pend.P = -1; g->pend.prefold = prefold;
     if (radius_rows) *radius_rows = R;
     return CG_OK;
 }
@@ -1680,8 +1709,11 @@ int cg_stencil_interior(cg_grid* g) {
 }
 
 int cg_stencil_finish(cg_grid* g) {
-    NEED(g);
-    if (!g->pend.active) return fail(g, CG_ERR_STATE, "no stencil step is open");
+    NEED_H0(g);
+    if (!g->pend.active) { NEED(g); return fail(g, CG_ERR_STATE, "no stencil step is open"); }
+    // (a run of vertical steps left waiting for this deposit stays in its queue for now)
+    const bool waiting = g->pend.prefold && !g->lat.active && !g->vq.empty() && g->vq[0].fresh;
+    if (!waiting) { g->pend.prefold = false; NEED(g); }
     const bool etch = g->pend.kind == CG_STENCIL_ETCH;
     if (!etch && !g->pend.interior_done) { int rc = stencil_prepare_deposit(g); if (rc) { g->pend.active = false; return rc; } }
     Pending p = g->pend;
@@ -1701,15 +1733,18 @@ int cg_stencil_finish(cg_grid* g) {
     // inside its launch (flush_vertical).  Only when nothing of what the host tracks needs the device before that.
     static const bool no_fold = getenv("CG_NO_FOLD") != nullptr;
     if (!no_fold && g->fuse && !g->stats_on && g->split && part == PART_ALL && !halo_lo && !halo_up && !p.may_overflow && g->nx == g->nx_global &&
-        g->N % 4 == 0 && !g->has_gaps && !g->has_cavity && g->len_bound + 1 <= g->lmax_vis && p.K->Re <= LEAN_FOLD_MAX_R) {
+        g->N % 4 == 0 && !g->has_gaps && !g->has_cavity && g->len_bound + 1 <= g->lmax_vis && (p.K->Re <= LEAN_FOLD_MAX_R || (p.prefold && !g->vq.empty()))) {
         const StencilForm form = stencil_form(g, p.K, false, p.mat, -1, false);
         if (form.streams && form.lean) {
+            g->lat.pre.clear();
+            if (p.prefold) g->lat.pre.swap(g->vq);             // the waiting run goes with it
             g->lat.active = true; g->lat.mask = mask; g->lat.mat = p.mat; g->lat.t_eff = p.t_eff; g->lat.R = p.R; g->lat.K = p.K; g->lat.P = p.P;
             g->len_valid = false;
             if (g->len_bound < 255) g->len_bound += 1;
             return CG_OK;
         }
     }
+    if (p.prefold) { int rcf = flush_vertical(g); if (rcf) return rcf; rcf = materialize(g); if (rcf) return rcf; }      // not this time: the run first
     int rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, p.P, part, p.may_overflow); if (rc) return rc;
     if (p.may_overflow) {
         int fl[4]; rc = read_flags(g, fl); if (rc) return rc;
@@ -2358,7 +2393,7 @@ int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
 int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8_t* len, int lmax) {
     NEED_H0(g);
     if (!mat || !zpair || !len || lmax < 1 || lmax > 256) return fail(g, CG_ERR_ARG, "bad upload arguments (lmax=%d)", lmax);
-    g->vq.clear(); g->lat.active = false;                       // every column is replaced: queued vertical steps are dropped, not launched
+    g->vq.clear(); g->lat.active = false; g->lat.pre.clear();                       // every column is replaced: queued vertical steps are dropped, not launched
     g->pend.active = false;
     HIPCHK(g, hipStreamSynchronize(g->stream));
     if (lmax > g->lmax) { int rc = grow_planes(g, lmax - g->lmax); if (rc) return rc; }
@@ -2420,7 +2455,7 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     NEED_H0(g);
     auto it = g->snaps.find(slot);
     if (it == g->snaps.end()) return fail(g, CG_ERR_ARG, "no snapshot in slot %d", slot);
-    g->vq.clear(); g->lat.active = false;                       // the grid is replaced: queued vertical steps are dropped, not launched
+    g->vq.clear(); g->lat.active = false; g->lat.pre.clear();                       // the grid is replaced: queued vertical steps are dropped, not launched
     const Snapshot& s = it->second;
     g->pend.active = false;
     if (s.planes > g->lmax) { int rc = grow_planes(g, (s.planes - g->lmax + 15) / 16 * 16); if (rc) return rc; }
