@@ -230,11 +230,13 @@ def main():
 
         # ---- pass 0 (untimed): per-step column counts for the algorithmic-byte model
         grid.stats_enable(True)
-        step_bytes, step_check = [], []
+        step_bytes, step_bytes_in, step_check = [], [], []
         slab.createNewGrid()
         for s in flow:
             flows.apply_step(slab, s, masks)
-            step_bytes.append(flows.algorithmic_bytes(s["kind"], grid.stats()))
+            st = grid.stats()
+            step_bytes.append(flows.algorithmic_bytes(s["kind"], st))
+            step_bytes_in.append(flows.algorithmic_bytes(s["kind"], st, in_pass=True))
             step_check.append(slab.checksum())
         grid.stats_enable(False)
 
@@ -294,74 +296,79 @@ def main():
         # cross-sections of C5, the end of the timed region.  The same rule here says which launch a step's bytes belong to.
         FUSE_MAX = 6
         fusing = not os.environ.get("CG_NO_FUSE")
-        kbytes, run, fused_launches, fused_steps = {}, [], 0, 0
-
-        def close_run():
-            nonlocal fused_launches, fused_steps
-            if len(run) >= 2:
-                kbytes["k_vertical_fused"] = kbytes.get("k_vertical_fused", 0) + sum(step_bytes[i] for i in run)
-                fused_launches += 1; fused_steps += len(run)
-            elif run:
-                kd1 = kind_of(flow[run[0]])
-                kbytes[kd1] = kbytes.get(kd1, 0) + step_bytes[run[0]]
-            run.clear()
-        # A lateral deposit of radius <= 4 on an undivided grid waits for the vertical steps behind it (up to FUSE_MAX - 1)
-        # and applies them inside its own launch (k_stencil_lean's FOLD form): their bytes then belong to that launch.
-        folding = fusing and world == 1 and not os.environ.get("CG_NO_FOLD")
-        fold_left, folded_steps, folded_launches, last_lateral, prefolded = 0, 0, 0, -1, False
+        # A lateral deposit on an undivided grid takes vertical steps along inside its own launch (k_stencil_lean): up to
+        # FUSE_MAX - 1 that follow it when its radius is <= 4 (FOLD form), and, without a mask, the run that was waiting on
+        # the reset grid in front of it (FRESH form).
+        folding = fusing and world == 1 and not os.environ.get("CG_NO_FOLD") and not slice_idx
         FOLDED = "k_stencil<deposit+vertical>"
+        launches, cur = [], None              # (kernel group, [step indices]); cur = a launch that may still take steps: [kind, steps, room]
+
+        def close():
+            nonlocal cur
+            if cur:
+                kind, steps, _ = cur
+                if kind == "run":
+                    launches.append(("k_vertical_fused" if len(steps) >= 2 else kind_of(flow[steps[0]]), steps))
+                else:
+                    launches.append((FOLDED if len(steps) >= 2 else "k_stencil<deposit>", steps))
+            cur = None
         for q in range(total_steps):
             idx = (k + q) % len(flow)
             kd = kind_of(flow[idx])
             if idx == 0:
-                close_run(); fold_left = 0
-            if kd.startswith("k_vertical") and fusing:
-                if fold_left > 0 and not run:
-                    if fold_left == FUSE_MAX - 1 and not prefolded:      # the first step behind the deposit: that launch is of the other kind
-                        folded_launches += 1
-                        kbytes["k_stencil<deposit>"] -= step_bytes[last_lateral]
-                        kbytes[FOLDED] = kbytes.get(FOLDED, 0) + step_bytes[last_lateral]
-                    prefolded = False
-                    kbytes[FOLDED] += step_bytes[idx]
-                    fold_left -= 1; folded_steps += 1
-                    if slice_idx:
-                        fold_left = 0
-                    continue
-                run.append(idx)
-                # (the run that starts on the reset grid goes out as one table look-up of up to 16 steps)
-                if len(run) == (16 if run[0] == 0 else FUSE_MAX) or slice_idx:
-                    close_run()
+                close()
+            if kd.startswith("k_vertical"):
+                if not fusing:
+                    launches.append((kd, [idx])); continue
+                if cur and cur[2] > 0:
+                    cur[1].append(idx); cur[2] -= 1
+                else:
+                    close()
+                    # (the run that starts on the reset grid goes out as one table look-up of up to 16 steps)
+                    cur = ["run", [idx], (16 if idx == 0 else FUSE_MAX) - 1]
+                if cur[2] == 0 or slice_idx:
+                    close()
             else:
                 s_ = flow[idx]
-                lat = max(0.0, s_["t"]) * max(0.0, min(1.0, s_["S"]))
-                # the run waiting on the reset grid goes out inside a lateral deposit without a mask that follows it (FRESH form)
-                if folding and run and run[0] == 0 and kd == "k_stencil<deposit>" and s_["mask"] is None and not slice_idx:
-                    kbytes[FOLDED] = kbytes.get(FOLDED, 0) + sum(step_bytes[i] for i in run) + step_bytes[idx]
-                    folded_steps += len(run); folded_launches += 1
-                    run.clear()
-                    last_lateral = idx
-                    kbytes.setdefault("k_stencil<deposit>", 0)
-                    if math.ceil(lat / 2.0) <= 4:
-                        fold_left = FUSE_MAX - 1; prefolded = True
+                small = math.ceil(max(0.0, s_["t"]) * max(0.0, min(1.0, s_["S"])) / 2.0) <= 4
+                if folding and kd == "k_stencil<deposit>" and cur and cur[0] == "run" and cur[1][0] == 0 and s_["mask"] is None:
+                    cur = ["lat", cur[1] + [idx], FUSE_MAX - 1 if small else 0]
+                    if cur[2] == 0:
+                        close()
                     continue
-                close_run()
-                kbytes[kd] = kbytes.get(kd, 0) + step_bytes[idx]
-                last_lateral = idx
-                fold_left = FUSE_MAX - 1 if (folding and kd == "k_stencil<deposit>" and math.ceil(lat / 2.0) <= 4 and not slice_idx) else 0
-        close_run()
+                close()
+                if folding and kd == "k_stencil<deposit>" and small:
+                    cur = ["lat", [idx], FUSE_MAX - 1]
+                else:
+                    launches.append((kd, [idx]))
+        close()
+        # Algorithmic bytes per kernel group.  The first step of a launch is charged as on its own (it reads the column's
+        # length and top layer); a step applied further down the same launch finds them in registers and is charged its
+        # mask byte, what it writes and the deeper layers it has to read (flows.algorithmic_bytes(in_pass=True)).
+        kbytes, kbytes_steps = {}, {}
+        for grp, steps in launches:
+            kbytes[grp] = kbytes.get(grp, 0) + step_bytes[steps[0]] + sum(step_bytes_in[i] for i in steps[1:])
+            kbytes_steps[grp] = kbytes_steps.get(grp, 0) + sum(step_bytes[i] for i in steps)
+        fused_launches = sum(1 for grp, st in launches if grp == "k_vertical_fused")
+        fused_steps = sum(len(st) for grp, st in launches if grp == "k_vertical_fused")
+        folded_launches = sum(1 for grp, st in launches if grp == FOLDED)
+        folded_steps = sum(len(st) - 1 for grp, st in launches if grp == FOLDED)
         kernels = {}
         for name, (ms, cnt) in prof.items():
             kernels[name] = {"ms_total": round(ms, 4), "launches": cnt, "ms_avg": round(ms / cnt, 4)}
             if name in kbytes and ms > 0:
                 kernels[name]["algorithmic_GB"] = round(kbytes[name] / 1e9, 3)
                 kernels[name]["GBps"] = round(kbytes[name] / 1e9 / (ms / 1e3), 1)
-        # the roofline object is about ONE step's kernel: a fused launch's algorithmic bytes are the sum of its steps', which
-        # says how much traffic the fusion saved, not how close the launch runs to the memory rate
+                expect = sum(1 for grp, _ in launches if grp == name)
+                if expect != cnt:                           # the rule above and the library disagree on what went out together
+                    kernels[name]["launches_by_bench_rule"] = expect
+                if kbytes_steps[name] != kbytes[name]:      # what the same steps move when every one is a pass of its own
+                    kernels[name]["algorithmic_GB_step_by_step"] = round(kbytes_steps[name] / 1e9, 3)
+        # the roofline object is about the group of launches that takes the most time
         MULTI = ("k_vertical_fused", FOLDED)          # groups whose launches apply several steps
-        cand = {n_: v for n_, v in kernels.items() if "GBps" in v and n_ not in MULTI}
-        if not cand:                              # a flow of vertical steps only (C2): nothing but fused launches to report
-            cand = {n_: v for n_, v in kernels.items() if "GBps" in v}
+        cand = {n_: v for n_, v in kernels.items() if "GBps" in v}
         dom = max(cand, key=lambda n_: cand[n_]["ms_total"]) if cand else None
+        pick_later = dom in MULTI                  # (settled below, once the traffic file has been looked at)
         roofline = None
         # HBM traffic per launch from the PMC passes of the same command (tools/prof.sh), when committed: the file holds
         # fetch + write bytes per launch of every kernel group; those and the live launch times give the rate at which
@@ -387,19 +394,31 @@ def main():
                 if dom in tk:
                     traffic = kernels[dom]["traffic_bytes_per_launch"]
                     traffic_src = {"file": os.path.relpath(tpath, ROOT), "git_blob": git_blob_hash(tpath)}
+        if pick_later and cand[dom].get("traffic_GBps") is None:
+            # no measured traffic for this workload: the group of single-step launches that takes the most time, if there is one
+            single = {n_: v for n_, v in cand.items() if n_ not in MULTI}
+            if single:
+                dom = max(single, key=lambda n_: single[n_]["ms_total"])
         if dom:
             achieved = cand[dom]["GBps"]
             note = None
-            if dom in MULTI:
-                # only fused launches ran (a flow of vertical steps): the sum of the fused steps' bytes over the launch time
-                # is not a memory rate (it passes the peak), so the rate given is the measured traffic's, or none
-                achieved = cand[dom].get("traffic_GBps")
-                note = ("every launch applies a run of vertical steps in one pass; achieved = PMC traffic per launch / launch time"
-                        if achieved is not None else
-                        "every launch applies a run of vertical steps in one pass: no per-step memory rate exists and no PMC traffic file covers this workload")
+            if dom in MULTI and cand[dom].get("traffic_GBps") is not None:
+                # several steps per launch: no per-step byte count describes the launch (intermediate states never reach
+                # memory), so the rate given is the one at which it really moves bytes
+                achieved = cand[dom]["traffic_GBps"]
+                note = ("a launch of this group applies several process steps in one pass over the columns; achieved = HBM bytes per launch "
+                        "(rocprofv3 PMC, traffic_source) / launch time.  kernels[...].GBps is the algorithmic figure: the first step of a launch "
+                        "charged in full, each further one its mask byte, what it writes and the deeper layers it reads")
+            elif dom in MULTI:
+                # nothing but multi-step launches ran and no traffic file covers the workload (C2 at a size that stays in
+                # the caches): the algorithmic figure of such launches is not a memory rate, so none is given
+                achieved = None
+                note = ("every launch applies a run of process steps in one pass over the columns and no PMC traffic file covers this workload: "
+                        "no memory rate is given (kernels[...].GBps charges the first step of a launch in full and each further one its "
+                        "mask byte, what it writes and the deeper layers it reads)")
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                         "frac": round(achieved / 8000.0, 4) if achieved is not None else None, "note": note, "traffic": traffic, "traffic_source": traffic_src,
-                        "launches": cand[dom]["launches"], "ms_avg": cand[dom]["ms_avg"], "fused_steps_per_launch": (fused_steps / max(1, fused_launches)) if dom == "k_vertical_fused" else 1,
+                        "launches": cand[dom]["launches"], "ms_avg": cand[dom]["ms_avg"], "steps_per_launch": round(sum(len(st) for grp, st in launches if grp == dom) / max(1, sum(1 for grp, st in launches if grp == dom)), 2),
                         "algorithmic_bytes_per_launch": int(kbytes[dom] / max(1, cand[dom]["launches"]))}
         total_alg = sum(step_bytes[(k + q) % len(flow)] for q in range(total_steps))
         total_s = sum(region_s)
@@ -423,8 +442,9 @@ def main():
             "whole_flow_traffic_GBps": round(flow_traffic * world / 1e9 / total_s, 1) if flow_traffic else None,
             "fusion": {"vertical_steps_fused": fused_steps, "fused_launches": fused_launches,
                        "vertical_steps_inside_lateral_deposits": folded_steps, "lateral_deposits_with_steps_inside": folded_launches,
-                       "note": "runs of consecutive vertical steps are applied in one pass over the columns (k_vertical_fused); "
-                               "its algorithmic bytes are the sum of its steps', so its GB/s is not an HBM rate; CG_NO_FUSE=1 launches every step on its own"},
+                       "note": "runs of consecutive vertical steps are applied in one pass over the columns: in a launch of their own "
+                               "(k_vertical_fused) or inside the lateral deposit in front of or behind them (k_stencil<deposit+vertical>); "
+                               "CG_NO_FOLD=1 keeps them out of the lateral launches, CG_NO_FUSE=1 launches every step on its own"},
             "checksum": "%016x" % check,
             "roofline": roofline, "kernels": kernels,
         }

@@ -1342,8 +1342,9 @@ int cg_destroy(cg_grid* g) {
 }
 
 int cg_reset(cg_grid* g, int lmax_init) {
-    NEED_H0(g);
-    g->vq.clear(); g->lat.active = false; g->lat.pre.clear();                       // queued vertical steps would be wiped out anyway: dropped, not launched
+    // (steps still waiting in the queue are launched first although the reset wipes out what they do: a step that was
+    // asked for is a step that runs, whoever times the calls)
+    NEED_H(g);
     int lmax = next_pow2(lmax_init > 0 ? lmax_init : g->lmax_vis);
     if (lmax > 256) lmax = 256;
     g->pend.active = false;
@@ -1367,7 +1368,7 @@ int cg_raise_lmax(cg_grid* g, int lmax) {
     return CG_OK;
 }
 
-int cg_clear(cg_grid* g) { NEED_H0(g); g->vq.clear(); g->lat.active = false; g->lat.pre.clear(); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
+int cg_clear(cg_grid* g) { NEED_H(g); g->pend.active = false; return zero_planes(g, g->len_bound > g->lmax); }
 
 int cg_get_info(const cg_grid* g, cg_info* o) {
     if (!g || !o) return CG_ERR_ARG;
@@ -2393,7 +2394,7 @@ int cg_download(cg_grid* g, uint8_t* mat, uint16_t* zpair, uint8_t* len) {
 int cg_upload(cg_grid* g, const uint8_t* mat, const uint16_t* zpair, const uint8_t* len, int lmax) {
     NEED_H0(g);
     if (!mat || !zpair || !len || lmax < 1 || lmax > 256) return fail(g, CG_ERR_ARG, "bad upload arguments (lmax=%d)", lmax);
-    g->vq.clear(); g->lat.active = false; g->lat.pre.clear();                       // every column is replaced: queued vertical steps are dropped, not launched
+    { int rcf = flush_vertical(g); if (rcf) return rcf; }       // (what is queued runs, although every column is replaced)
     g->pend.active = false;
     HIPCHK(g, hipStreamSynchronize(g->stream));
     if (lmax > g->lmax) { int rc = grow_planes(g, lmax - g->lmax); if (rc) return rc; }
@@ -2455,7 +2456,7 @@ int cg_snapshot_load(cg_grid* g, int slot) {
     NEED_H0(g);
     auto it = g->snaps.find(slot);
     if (it == g->snaps.end()) return fail(g, CG_ERR_ARG, "no snapshot in slot %d", slot);
-    g->vq.clear(); g->lat.active = false; g->lat.pre.clear();                       // the grid is replaced: queued vertical steps are dropped, not launched
+    { int rcf = flush_vertical(g); if (rcf) return rcf; }       // (what is queued runs, although the grid is replaced)
     const Snapshot& s = it->second;
     g->pend.active = false;
     if (s.planes > g->lmax) { int rc = grow_planes(g, (s.planes - g->lmax + 15) / 16 * 16); if (rc) return rc; }

@@ -227,8 +227,12 @@ def apply_step(grid, step, masks):
 # ---------------------------------------------------------------------------------------------
 # algorithmic bytes of a step (reference field sizes: len 1, mat 1, z0q 2, z1q 2, mask 1)
 # ---------------------------------------------------------------------------------------------
-def algorithmic_bytes(step_kind, stats):
+def algorithmic_bytes(step_kind, stats, in_pass=False):
     """stats = cg_step_stats of the step: [visited, open, extended, appended, etched, removed, floor_scanned, -].
+
+    in_pass: the step is applied in the same pass over the columns as a step before it (a fused or folded launch), so
+    the column's length and top layer are at hand: it is charged its mask byte per column, what it writes (extend 2 B,
+    append 6 B; etch z1 + len 3 B and 5 B per removed layer) and the deeper layers it reads (5 B per removed layer).
 
     deposit (vertical or conformal, fused): extend 7 B (R len, mask, top mat, top z1; W z1),
     append 11 B (R 5; W mat, z0, z1, len), any other column 2 B (mask, len).
@@ -237,6 +241,10 @@ def algorithmic_bytes(step_kind, stats):
     isotropic etch adds 3 B per layer scanned for the floor.
     """
     n, _open, ext, app, etched, removed, floor = stats[:7]
+    if in_pass:
+        if step_kind in ("SUBSTR", "DEPO"):
+            return n + 2 * ext + 6 * app
+        return n + 3 * etched + 10 * removed + 3 * floor
     if step_kind in ("SUBSTR", "DEPO"):
         return 2 * (n - ext - app) + 7 * ext + 11 * app
     return 2 * (n - etched) + 9 * etched + 11 * removed + 3 * floor

@@ -55,7 +55,7 @@ def parse(k):
     args = [a.strip() for a in m.group(2).split(",")]
     kind = m.group(1)
     if kind in ("stencil_stream", "stencil_lean"):   # <R, ETCH, ...>: never keep statistics
-        if kind == "stencil_lean" and len(args) > 3 and args[3] == "true":      # FOLD: the vertical steps behind a deposit inside its launch
+        if kind == "stencil_lean" and "true" in args[3:5]:      # FOLD / FRESH: the vertical steps behind / in front of a deposit inside its launch
             return "k_stencil<deposit+vertical>", False
         return "k_stencil<%s>" % ("etch" if args[1] == "true" else "deposit"), False
     if kind == "stencil_sym":             # <R, TJS, ETCH, STATS>
