@@ -18,14 +18,16 @@
  * All work of a handle is enqueued on one HIP stream (its own, or the one given to
  * cg_set_stream); entry points that return data to the host synchronise that stream.
  * Vertical steps (cg_deposit_general / cg_etch_general / cg_stencil_begin with t*S < min(dx, dy))
- * are queued in the handle, up to six, and launched together by the next entry point that is not
- * such a step (cg_sync included): same results, one pass over the columns instead of one per step.
+ * are queued in the handle, up to six (sixteen on a grid that has just been reset), and launched
+ * together by the next entry point that is not such a step (cg_sync included): same results, one
+ * pass over the columns instead of one per step.  A lateral deposit on an undivided grid may wait in
+ * the same way for the vertical steps that follow it (up to five), which then run inside its launch.
  * Consequences for a caller that brings its own stream (cg_set_stream): when such a call returns,
  * nothing of it may be on the stream yet -- an event recorded, or dependent work enqueued, right
  * after it does not wait for the step.  cg_sync, cg_get_stream or any entry point other than a
  * vertical step puts the queued steps on the stream first; a launch error of a queued step is
  * reported by that later call.  cg_reset, cg_clear, cg_upload and cg_snapshot_load replace every
- * column: steps still queued are dropped, not launched.
+ * column; steps still queued are launched first all the same.
  *
  * The comment above each declaration names the reference interface it stands in for.
  * "cg1/cg2/rt/sl" = template/script_columngrid.js, script_columngrid2.js,
