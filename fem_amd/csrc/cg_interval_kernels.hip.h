@@ -486,7 +486,80 @@ __device__ __forceinline__ void insert_runs(const GridView& s, const GridView& d
 // to [0, Hcap] and quantised (cg2:542-557).  exact: the host has checked that the quantised ends are x - lo_q and y + hi_q
 // for EVERY integer x, y (add / zs is further than 1e-6 from a rounding boundary, where the double arithmetic of the
 // reference, good to 1e-10 steps here, cannot end on the other side), so the kernel works in integers for this tap.
-struct AldTap { int du, dv; double add; int lo_q, hi_q, exact, pad_; };
+struct AldTap { int du, dv; double add; int lo_q, hi_q, exact, cls; };      // cls: taps with the same `add` (same distance) share a class, see k_ald_grow
+
+// The quantised range [q0, q1) a seed grows to under a tap, or false (cg2:542-557).  In integers when the tap allows
+// it and the lower end stays a step clear of the cap (neither of the reference's two "empty after clipping" exits can
+// then be taken: the range is 2*add > 1e-6 long before clipping, and at least most of a step long after it).
+__device__ __forceinline__ bool ald_seed_range(const uint2 sd, const AldTap& tp, double zs, double inv_zs, double Hcap, int HcapQ, int& q0, int& q1) {
+    if (tp.exact && (int)sd.x - tp.lo_q < HcapQ - 1) {
+        q0 = max(0, (int)sd.x - tp.lo_q);
+        q1 = min(HcapQ, (int)sd.y + tp.hi_q); if (q1 <= q0) q1 = q0 + 1;
+        return true;
+    }
+    const double add = tp.add;
+    const double lo = (double)sd.x * zs - add, hi = (double)sd.y * zs + add;
+    if (hi <= lo + CG_EPS) return false;
+    const double z0 = lo > 0 ? lo : 0, z1 = hi < Hcap ? hi : Hcap;
+    if (z1 <= z0 + CG_EPS) return false;
+    double d0 = js_round(z0 * inv_zs); if (d0 < 0) d0 = 0;
+    double d1 = js_round(z1 * inv_zs); if (d1 <= d0) d1 = d0 + 1;
+    q0 = (int)d0; q1 = (int)d1;
+    return true;
+}
+
+// --- the seeds of every column grown once per tap class --------------------------------------------------------------
+// A coat evaluates, for every column, every tap and every seed of the column the tap points at, the range that seed
+// grows to, and ORs it into the column's bitset (computeCoatBitsSingleT, cg2:499-583).  The range depends on the seed and
+// on the tap's `add` only, and taps at the same distance share their add: a 29-tap kernel has 7 distinct ones.  So the
+// ranges of a column's seeds are worked out once per class here -- with markRangeQ's word-boundary behaviour applied to
+// each (a range that ends on a multiple of 32 sets [q0, q1 - 32) or nothing, see the top of this file), then united
+// where they touch or overlap, which is exact for the bits they set -- and the coat kernel ORs the united runs: one or
+// two per (column, class) where the seeds were four or ten.  Up to ALD_RUNS runs are kept per (column, class); a column
+// with more says so (ALD_RUNS_MANY) and the coat kernel goes back to its seeds.
+constexpr int ALD_RUNS = 3;
+constexpr int ALD_RUNS_MANY = 255;
+static __global__ __launch_bounds__(256) void k_ald_grow(const uint16_t* __restrict__ seed_n, const uint2* __restrict__ seed, int seed_planes, size_t stride,
+                                                  const AldTap* __restrict__ cls_taps, int ncls, double zs, double inv_zs, double Hcap, int HcapQ,
+                                                  uint8_t* __restrict__ runs_n, uint32_t* __restrict__ runs) {
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < stride; e += step) {
+        const int n = min((int)seed_n[e], seed_planes);
+        for (int c = 0; c < ncls; c++) {
+            const AldTap tp = cls_taps[c];
+            int ua[ALD_RUNS], ub[ALD_RUNS];
+#pragma unroll
+            for (int u = 0; u < ALD_RUNS; u++) { ua[u] = 0x7fffffff; ub[u] = -0x7fffffff - 1; }
+            bool many = false;
+            for (int q = 0; q < n; q++) {
+                int q0, q1;
+                if (!ald_seed_range(seed[(size_t)q * stride + e], tp, zs, inv_zs, Hcap, HcapQ, q0, q1)) continue;
+                if ((q1 & 31) == 0) { q1 -= 32; if (q1 <= q0) continue; }
+                bool placed = false;
+#pragma unroll
+                for (int u = 0; u < ALD_RUNS; u++) {
+                    const bool hit = !placed && q0 <= ub[u] && q1 >= ua[u];
+                    ua[u] = hit ? min(ua[u], q0) : ua[u]; ub[u] = hit ? max(ub[u], q1) : ub[u];
+                    placed |= hit;
+                }
+#pragma unroll
+                for (int u = 0; u < ALD_RUNS; u++) {
+                    const bool take = !placed && ub[u] < ua[u];
+                    ua[u] = take ? q0 : ua[u]; ub[u] = take ? q1 : ub[u];
+                    placed |= take;
+                }
+                if (!placed) { many = true; break; }
+            }
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < ALD_RUNS; u++) {
+                if (ub[u] > ua[u]) { runs[((size_t)c * ALD_RUNS + cnt) * stride + e] = (uint32_t)ua[u] | ((uint32_t)ub[u] << 16); cnt++; }
+            }
+            runs_n[(size_t)c * stride + e] = many ? (uint8_t)ALD_RUNS_MANY : (uint8_t)cnt;
+        }
+    }
+}
+
 
 // --- coat at thickness t (computeCoatBitsSingleT + applyCoatFromBits, cg2:699-707, 585-682) --
 // bbox = the seeds' bounding box grown by the kernel radius and clipped to the domain (cg2:510-524).
@@ -497,25 +570,8 @@ static __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hc
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const BitCol fill{lds + threadIdx.x, (int)blockDim.x, L.wpc};
     const int lane = threadIdx.x & 63, nl = min(64, (int)blockDim.x);      // lanes of this wave (a block is 2^k threads)
-    // the quantised range [q0, q1) a seed grows to under a tap, or false (cg2:542-557)
     auto seed_range = [&](const uint2 sd, const AldTap& tp, int& q0, int& q1) -> bool {
-        // In integers when the tap allows it and the lower end stays a step clear of the cap (neither of the
-        // reference's two "empty after clipping" exits can then be taken: the range is 2*add > 1e-6 long before
-        // clipping, and at least most of a step long after it).
-        if (tp.exact && (int)sd.x - tp.lo_q < HcapQ - 1) {
-            q0 = max(0, (int)sd.x - tp.lo_q);
-            q1 = min(HcapQ, (int)sd.y + tp.hi_q); if (q1 <= q0) q1 = q0 + 1;
-            return true;
-        }
-        const double add = tp.add;
-        const double lo = (double)sd.x * s.zs - add, hi = (double)sd.y * s.zs + add;
-        if (hi <= lo + CG_EPS) return false;
-        const double z0 = lo > 0 ? lo : 0, z1 = hi < Hcap ? hi : Hcap;
-        if (z1 <= z0 + CG_EPS) return false;
-        double d0 = js_round(z0 * s.inv_zs); if (d0 < 0) d0 = 0;
-        double d1 = js_round(z1 * s.inv_zs); if (d1 <= d0) d1 = d0 + 1;
-        q0 = (int)d0; q1 = (int)d1;
-        return true;
+        return ald_seed_range(sd, tp, s.zs, s.inv_zs, Hcap, HcapQ, q0, q1);
     };
     // (the loop runs the same number of times in every lane: the lanes of a wave work together further down)
     for (size_t base = (size_t)blockIdx.x * blockDim.x; base < s.N; base += stride) {
@@ -629,6 +685,98 @@ static __global__ void k_ald_coat(GridView s, GridView d, AldLayout L, double Hc
             __builtin_amdgcn_wave_barrier();
         }
         if (!inside) continue;
+#pragma unroll
+        for (int u = 0; u < NU; u++) if (ub[u] > ua[u]) mark_range_exact(fill, ua[u], ub[u]);
+        mark_occupied<true>(s, c, fill);                       // fill & ~occ, cg2:566-582
+        fill.set(L.wpc - 1, fill.get(L.wpc - 1) & L.lastMask);
+        insert_runs(s, d, c, fill, L.Zmax, mat, flags);
+    }
+}
+
+// --- the coat from the grown runs (the usual path; k_ald_coat above when heights pass 16 bits or CG_ALD_SEEDS=1) --------
+// One lane per column, all taps in step: the runs of the column a tap points at, for the tap's class, are united in the
+// lane's registers with what the other taps brought and reach the bitset only when they touch none of three running
+// unions.  A (column, class) that holds more runs than k_ald_grow keeps is evaluated from its seeds, in the lane.
+static __global__ void k_ald_coat_runs(GridView s, GridView d, AldLayout L, double Hcap, const AldTap* __restrict__ taps, int ntaps,
+                                const uint16_t* __restrict__ seed_n, const uint2* __restrict__ seed, int seed_planes, ArrLayout S,
+                                const uint8_t* __restrict__ runs_n, const uint32_t* __restrict__ runs,
+                                int imin, int imax, int jmin, int jmax, int mat, int HcapQ, int* __restrict__ flags) {
+    extern __shared__ uint32_t lds[];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const BitCol fill{lds + threadIdx.x, (int)blockDim.x, L.wpc};
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < s.N; c += stride) {
+        const int i = (int)(c / s.ny), j = (int)(c - (size_t)i * s.ny);
+        fill.clear();
+        constexpr int NU = 3;
+        int ua[NU], ub[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) { ua[u] = 0x7fffffff; ub[u] = -0x7fffffff - 1; }
+        auto add_bits = [&](int q0, int q1) {                 // exactly the bits of [q0, q1); q1 < q0: nothing
+            bool placed = q1 < q0;
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const bool hit = !placed && q0 <= ub[u] && q1 >= ua[u];
+                ua[u] = hit ? min(ua[u], q0) : ua[u]; ub[u] = hit ? max(ub[u], q1) : ub[u];
+                placed |= hit;
+            }
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const bool take = !placed && ub[u] < ua[u];
+                ua[u] = take ? q0 : ua[u]; ub[u] = take ? q1 : ub[u];
+                placed |= take;
+            }
+            if (!__ballot(!placed)) return;
+            if (!placed) {
+                mark_range_exact(fill, ua[0], ub[0]);
+#pragma unroll
+                for (int u = 0; u + 1 < NU; u++) { ua[u] = ua[u + 1]; ub[u] = ub[u + 1]; }
+                ua[NU - 1] = q0; ub[NU - 1] = q1;
+            }
+        };
+        // (32-bit entry numbers: the host checks that classes x runs x stride fits; a lane outside the seeds' box does the
+        // same loads at its own column and drops them, so that every branch below is one the whole wave takes or skips)
+        const bool in_box = i >= imin && i <= imax && j >= jmin && j <= jmax;
+        const unsigned own = (unsigned)S.at(s, i, j), ustride = (unsigned)S.stride;
+        for (int t0 = 0; t0 < ntaps; t0 += 4) {
+            unsigned sc[4], at[4]; int nr[4]; uint32_t r0[4], r1[4], r2[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const AldTap& tp = taps[min(t0 + u, ntaps - 1)];
+                const int si = i - tp.du, sj = j - tp.dv;
+                const bool ok = in_box && t0 + u < ntaps && si >= -S.rows_lo && sj >= 0 && si < s.nx + S.rows_hi && sj < s.ny;
+                sc[u] = ok ? own - (unsigned)(tp.du * s.ny + tp.dv) : own;
+                nr[u] = runs_n[(unsigned)tp.cls * ustride + sc[u]];
+                at[u] = (unsigned)tp.cls * (unsigned)ALD_RUNS * ustride + sc[u];
+                if (!ok) nr[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                r0[u] = runs[at[u]];
+                r1[u] = __ballot(nr[u] >= 2 && nr[u] != ALD_RUNS_MANY) ? runs[at[u] + ustride] : 0u;
+                r2[u] = __ballot(nr[u] >= 3 && nr[u] != ALD_RUNS_MANY) ? runs[at[u] + 2 * ustride] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool many = nr[u] == ALD_RUNS_MANY;
+                if (__ballot(many)) {                         // more runs than are kept: from the seeds (markRangeQ's rule as in k_ald_grow)
+                    if (many) {
+                        const AldTap tp = taps[t0 + u];
+                        const int n = min((int)seed_n[sc[u]], seed_planes);
+                        for (int q = 0; q < n; q++) {
+                            int q0, q1;
+                            if (!ald_seed_range(seed[(size_t)q * S.stride + sc[u]], tp, s.zs, s.inv_zs, Hcap, HcapQ, q0, q1)) continue;
+                            if ((q1 & 31) == 0) { q1 -= 32; if (q1 <= q0) continue; }
+                            add_bits(q0, q1);
+                        }
+                    }
+                }
+                // an absent run is the empty range, which touches no union and takes no place
+                const int k = many ? 0 : nr[u];
+                add_bits(k >= 1 ? (int)(r0[u] & 0xffffu) : 0x7fffffff, k >= 1 ? (int)(r0[u] >> 16) : -0x7fffffff - 1);
+                if (__ballot(k >= 2)) add_bits(k >= 2 ? (int)(r1[u] & 0xffffu) : 0x7fffffff, k >= 2 ? (int)(r1[u] >> 16) : -0x7fffffff - 1);
+                if (__ballot(k >= 3)) add_bits(k >= 3 ? (int)(r2[u] & 0xffffu) : 0x7fffffff, k >= 3 ? (int)(r2[u] >> 16) : -0x7fffffff - 1);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < NU; u++) if (ub[u] > ua[u]) mark_range_exact(fill, ua[u], ub[u]);
         mark_occupied<true>(s, c, fill);                       // fill & ~occ, cg2:566-582

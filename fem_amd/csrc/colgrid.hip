@@ -152,6 +152,7 @@ struct cg_grid {
     int plane_budget = 256;                                // most planes the handle may map before it compacts instead (cg_set_plane_budget)
     // deposit_ALD: seeds of the exposed faces (plane-major like the grid), their bounding box, the tap table
     uint16_t* seed_n = nullptr; uint2* seed = nullptr; int seed_planes = 0; bool has_seeds = false;
+    uint32_t* ald_runs = nullptr; uint8_t* ald_runs_n = nullptr; size_t ald_runs_cap = 0;      // k_ald_grow's output for the coat in hand (ald_runs_cap = classes x seed_stride entries)
     int seed_bbox[4] = {0, -1, 0, -1}; uint64_t seed_total = 0;
     // a slab also holds the seeds of seed_rows rows of each neighbour: column (i, j) is entry seed_off + i*ny + j,
     // planes are seed_stride entries apart (a whole grid: seed_off = 0, seed_stride = N, no neighbour rows)
@@ -882,6 +883,9 @@ unsigned ald_blocks(size_t n, int bt) { return (unsigned)std::min<size_t>(std::m
 void drop_seeds(cg_grid* g) {
     if (g->seed_n) (void)hipFree(g->seed_n);
     if (g->seed) (void)hipFree(g->seed);
+    if (g->ald_runs) (void)hipFree(g->ald_runs);
+    if (g->ald_runs_n) (void)hipFree(g->ald_runs_n);
+    g->ald_runs = nullptr; g->ald_runs_n = nullptr; g->ald_runs_cap = 0;
     g->seed_n = nullptr; g->seed = nullptr; g->seed_planes = 0; g->has_seeds = false; g->seed_total = 0;
     g->seed_bbox[0] = 0; g->seed_bbox[1] = -1; g->seed_bbox[2] = 0; g->seed_bbox[3] = -1;
     g->seed_stride = g->seed_off = 0; g->seed_rows = 0; g->seed_lo = g->seed_hi = false;
@@ -935,6 +939,17 @@ int ald_coat(cg_grid* g, int mat, double t, const uint32_t* hmax_q = nullptr) {
         tp.exact = (!no_int && tp.add > 1e-6 && a < 1.0e6 && std::fabs(f - 0.5) > 1e-6 && g->zscale > 1e-6 && Hcap > 1e-6) ? 1 : 0;
         tp.lo_q = (int)std::ceil(std::min(a, 1.0e6) - 0.5); tp.hi_q = (int)std::floor(std::min(a, 1.0e6) + 0.5);
     }
+    // taps at the same distance share their `add`: one class each (k_ald_grow); the classes' taps go behind the kernel's own
+    const int ntaps = (int)taps.size();
+    std::vector<AldTap> classes;
+    for (AldTap& tp : taps) {
+        int c = -1;
+        for (size_t k = 0; k < classes.size(); k++) if (classes[k].add == tp.add) c = (int)k;
+        if (c < 0) { c = (int)classes.size(); classes.push_back(tp); }
+        tp.cls = c;
+    }
+    const int ncls = (int)classes.size();
+    taps.insert(taps.end(), classes.begin(), classes.end());
     if ((int)taps.size() > g->ald_taps_cap) {
         HIPCHK(g, hipStreamSynchronize(g->stream));
         if (g->d_ald_taps) (void)hipFree(g->d_ald_taps);
@@ -951,11 +966,38 @@ int ald_coat(cg_grid* g, int mat, double t, const uint32_t* hmax_q = nullptr) {
         imin = std::max(0, g->seed_bbox[0] - Rx); imax = std::min(g->nx - 1, g->seed_bbox[1] + Rx);
         jmin = std::max(0, g->seed_bbox[2] - Rx); jmax = std::min(g->ny - 1, g->seed_bbox[3] + Rx);
     }
-    const int ntaps = (int)taps.size();
     ProfScope ps(g, CG_K_OTHER);
+    // The seeds grown once per class and united (k_ald_grow), then the coat from those runs: unless a height does not fit the
+    // 16 bits a run's end is kept in, the runs find no memory, or CG_ALD_SEEDS=1 asks for the kernel that grows every seed
+    // under every tap.
+    static const bool from_seeds = getenv("CG_ALD_SEEDS") != nullptr;
+    bool use_runs = !from_seeds && HcapQ <= 65535 && ncls >= 1 && (size_t)ncls * ALD_RUNS * g->seed_stride < ((size_t)1 << 32);      // (32-bit entry numbers in the kernel)
+    if (use_runs) {
+        const size_t need = (size_t)ncls * g->seed_stride;
+        if (g->ald_runs_cap < need) {
+            HIPCHK(g, hipStreamSynchronize(g->stream));
+            if (g->ald_runs) (void)hipFree(g->ald_runs);
+            if (g->ald_runs_n) (void)hipFree(g->ald_runs_n);
+            g->ald_runs = nullptr; g->ald_runs_n = nullptr; g->ald_runs_cap = 0;
+            if (hipMalloc(&g->ald_runs, need * ALD_RUNS * sizeof(uint32_t)) != hipSuccess || hipMalloc(&g->ald_runs_n, need) != hipSuccess) {
+                (void)hipGetLastError();
+                if (g->ald_runs) (void)hipFree(g->ald_runs);
+                g->ald_runs = nullptr; g->ald_runs_n = nullptr; use_runs = false;
+            } else g->ald_runs_cap = need;
+        }
+    }
+    if (use_runs) {
+        hipLaunchKernelGGL(k_ald_grow, dim3(ald_blocks(g->seed_stride, 256)), dim3(256), 0, g->stream, g->seed_n, g->seed, g->seed_planes, g->seed_stride,
+                           g->d_ald_taps + ntaps, ncls, g->zscale, 1.0 / g->zscale, Hcap, HcapQ, g->ald_runs_n, g->ald_runs);
+        HIPCHK(g, hipGetLastError());
+    }
     return run_out_of_place(g, 0, "deposit_ALD", [&](GridView dst) {
-        hipLaunchKernelGGL(k_ald_coat, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), dst, L, Hcap, g->d_ald_taps, ntaps,
-                           g->seed_n, g->seed, g->seed_planes, seed_layout(g), imin, imax, jmin, jmax, mat, HcapQ, g->d_flags);
+        if (use_runs)
+            hipLaunchKernelGGL(k_ald_coat_runs, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), dst, L, Hcap, g->d_ald_taps, ntaps,
+                               g->seed_n, g->seed, g->seed_planes, seed_layout(g), g->ald_runs_n, g->ald_runs, imin, imax, jmin, jmax, mat, HcapQ, g->d_flags);
+        else
+            hipLaunchKernelGGL(k_ald_coat, dim3(ald_blocks(g->N, bt)), dim3(bt), lds, g->stream, view(g), dst, L, Hcap, g->d_ald_taps, ntaps,
+                               g->seed_n, g->seed, g->seed_planes, seed_layout(g), imin, imax, jmin, jmax, mat, HcapQ, g->d_flags);
     });
 }
 

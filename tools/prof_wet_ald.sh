@@ -26,7 +26,8 @@ print("# roofline (HBM, 8000 GB/s): algorithmic bytes of fem_amd/flows.py (wet_s
 for line in open("$OUT/trace.log"):
     if line.startswith("MODEL "):
         _, k, _, cnt, _, b = line.split()
-        c, ms = agg.get(k, (0, 0.0))
+        hit = [v for n_, v in agg.items() if n_.startswith(k)]        # (k_ald_coat: k_ald_coat_runs or k_ald_coat itself)
+        c, ms = sum(v[0] for v in hit), sum(v[1] for v in hit)
         if c == int(cnt) and ms > 0:
             r = int(b) / 1e9 / (ms / 1e3)
             print('{"kernel": "%s", "bound": "hbm", "launches": %d, "algorithmic_bytes_per_launch": %d, "ms_avg": %.3f, "achieved": %.1f, "peak": 8000.0, "unit": "GB/s", "frac": %.4f}' % (k, c, int(b) // c, ms / c, r, r / 8000.0))
