@@ -2,7 +2,8 @@
 // k_stencil_lean (textually, so that each kernel is compiled exactly as if the code stood in it).  Expects in scope:
 //   g (GridView), F (FusedOps), c0 (size_t: first of the 4 columns), open[FUSE_MAX] (mask bytes of step k, non-zero byte =
 //   open), r[4] (the tops, in and out), pushed[FUSE_MAX][4] (what deposit k pushed into its plane, 0 = nothing; filled in
-//   by the includer for the steps before KB), and the macro CG_FS_KB = first step to apply.
+//   by the includer for the steps before KB), and the macros CG_FS_KB = first step to apply, CG_FS_KE = one past the last
+//   (compile-time numbers: the steps outside them cost nothing).
 // CG_FS_PART 1: steps CG_FS_KB .. F.n-1.   CG_FS_PART 2: the stores of what deposits CG_FS_KB .. F.n-1 pushed.
 #if CG_FS_PART == 1
 #define CG_ON(w, j) (((w) & (0xffu << (8 * (j)))) != 0u)
@@ -11,7 +12,7 @@
     // on into further layers -- branch.)
 #pragma unroll
     for (int k = 0; k < FUSE_MAX; k++) {
-        if (k >= F.n || k < CG_FS_KB || !open[k]) continue;
+        if (k >= F.n || k < CG_FS_KB || k >= CG_FS_KE || !open[k]) continue;
         const FusedOp& op = F.op[k];
         const int matId = op.mat;
         const unsigned opn = open[k];
@@ -110,7 +111,7 @@
 #else
 #pragma unroll
     for (int k = 0; k < FUSE_MAX; k++) {
-        if (k >= F.n || k < CG_FS_KB || F.op[k].etch) continue;
+        if (k >= F.n || k < CG_FS_KB || k >= CG_FS_KE || F.op[k].etch) continue;
         const bool p0 = pushed[k][0] != 0, p1 = pushed[k][1] != 0, p2 = pushed[k][2] != 0, p3 = pushed[k][3] != 0;
         if (!(p0 || p1 || p2 || p3)) continue;
         const size_t at = (size_t)F.op[k].P * g.N + c0;

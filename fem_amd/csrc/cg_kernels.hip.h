@@ -649,21 +649,25 @@ __device__ __forceinline__ void fused_below4(const GridView& g, const FusedOps& 
 // The body of a run (cg_fused_steps.inc.h) as device functions: the FOLD form of k_stencil_lean calls these, while
 // k_vertical_fused below includes the text -- each of the two is compiled noticeably better its own way.
 // Steps KB .. F.n-1 of the run on the 4 columns at c0.
-template <int KB>
+template <int KB, int KE = FUSE_MAX>
 __device__ __forceinline__ void fused_steps(const GridView& g, const FusedOps& F, const size_t c0, const unsigned (&open)[FUSE_MAX], uint32_t (&r)[4],
                                             uint32_t (&pushed)[FUSE_MAX][4]) {
 #define CG_FS_KB KB
+#define CG_FS_KE KE
 #define CG_FS_PART 1
 #include "cg_fused_steps.inc.h"
 #undef CG_FS_PART
+#undef CG_FS_KE
 #undef CG_FS_KB
 }
-template <int KB>
+template <int KB, int KE = FUSE_MAX>
 __device__ __forceinline__ void fused_store_planes(const GridView& g, const FusedOps& F, const size_t c0, const uint32_t (&pushed)[FUSE_MAX][4]) {
 #define CG_FS_KB KB
+#define CG_FS_KE KE
 #define CG_FS_PART 2
 #include "cg_fused_steps.inc.h"
 #undef CG_FS_PART
+#undef CG_FS_KE
 #undef CG_FS_KB
 }
 
@@ -700,15 +704,19 @@ __global__ __launch_bounds__(256) void k_vertical_fused(GridView g, const FusedO
         pushed[k][0] = u; pushed[k][1] = u; pushed[k][2] = u; pushed[k][3] = u;
     }
 #define CG_FS_KB NUNI
+#define CG_FS_KE FUSE_MAX
 #define CG_FS_PART 1
 #include "cg_fused_steps.inc.h"
 #undef CG_FS_PART
+#undef CG_FS_KE
 #undef CG_FS_KB
     // the old tops every deposit of the run pushed, each into its own plane; then the tops
 #define CG_FS_KB 0
+#define CG_FS_KE FUSE_MAX
 #define CG_FS_PART 2
 #include "cg_fused_steps.inc.h"
 #undef CG_FS_PART
+#undef CG_FS_KE
 #undef CG_FS_KB
     if (F.fresh || r[0] != tv[0] || r[1] != tv[1] || r[2] != tv[2] || r[3] != tv[3]) {
         u32x4 nv; nv[0] = r[0]; nv[1] = r[1]; nv[2] = r[2]; nv[3] = r[3];

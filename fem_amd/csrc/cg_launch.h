@@ -14,6 +14,7 @@ struct StreamArgs {
     const FreshTab* fresh = nullptr;     // lean deposit without a mask: the run of vertical steps on the reset grid in front of it (FRESH form)
 };
 constexpr int LEAN_FOLD_MAX_R = 4;
+
 // k_stencil_stream<Re, etch, msg, masked> on `blocks` one-wave workgroups.  Re = 1..8 (larger: 8).
 void launch_stream(int Re, bool etch, bool msg, bool masked, unsigned blocks, hipStream_t stream, const StreamArgs& a);
 

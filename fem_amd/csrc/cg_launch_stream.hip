@@ -12,17 +12,21 @@ static void stream_one(bool etch, bool msg, bool masked, unsigned blocks, hipStr
     if (a.lean && !msg) {
         static const FusedOps none = {};
         static const FreshTab no_run = {};
-#define LL(E, K, F, W) hipLaunchKernelGGL((k_stencil_lean<RR, E, K, F, W>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.d_quad, a.so, \
+#define LL(E, K, NF, W) hipLaunchKernelGGL((k_stencil_lean<RR, E, K, NF, W>), dim3(blocks), dim3(64), 0, s, a.gv, a.mask, a.mat, a.t_eff, a.d_quad, a.so, \
                                           a.fold ? *a.fold : none, a.fresh ? *a.fresh : no_run)
+        constexpr int ANY = FUSE_MAX - 1;
+        const int behind = (a.fold && !etch) ? a.fold->n - 1 : 0;       // steps the launch takes along behind its deposit
         if (a.fresh && !etch && !masked) {                  // (the host asks for this form only where it exists)
-            if constexpr (RR <= LEAN_FOLD_MAX_R) { if (a.fold) { LL(false, false, true, true); return; } }
-            LL(false, false, false, true); return;
+            if constexpr (RR <= LEAN_FOLD_MAX_R) { if (behind > 0) { LL(false, false, ANY, true); return; } }
+            LL(false, false, 0, true); return;
         }
         if constexpr (RR <= LEAN_FOLD_MAX_R) {
-            if (a.fold && !etch) { if (masked) LL(false, true, true, false); else LL(false, false, true, false); return; }
+            if (behind == 1) { if (masked) LL(false, true, 1, false); else LL(false, false, 1, false); return; }
+            if (behind == 2) { if (masked) LL(false, true, 2, false); else LL(false, false, 2, false); return; }
+            if (behind > 2) { if (masked) LL(false, true, ANY, false); else LL(false, false, ANY, false); return; }
         }
-        if (etch) { if (masked) LL(true, true, false, false); else LL(true, false, false, false); }
-        else { if (masked) LL(false, true, false, false); else LL(false, false, false, false); }
+        if (etch) { if (masked) LL(true, true, 0, false); else LL(true, false, 0, false); }
+        else { if (masked) LL(false, true, 0, false); else LL(false, false, 0, false); }
 #undef LL
         return;
     }

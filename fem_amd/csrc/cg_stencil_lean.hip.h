@@ -16,6 +16,7 @@
 #pragma once
 #include "cg_kernels.hip.h"
 
+
 namespace cgk {
 
 // float32(q * zscale) under the deq_f32 licence (see StreamOpts)
@@ -48,9 +49,14 @@ constexpr int lean_waves(int R, bool etch, bool fold) { return R <= 3 ? ((etch |
 // of a column after that run is one of 2^masks records (FreshTab, see k_vertical_fresh): every row this tile reads is
 // put together from the run's mask bytes instead of being loaded, and the tile stores what the run's deposits pushed for
 // the rows it owns -- the run never gets a launch of its own, and its tops are never written or read.
-template <int R, bool ETCH, bool MASKED, bool FOLD = false, bool FRESH = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R, ETCH, FOLD)))) void k_stencil_lean(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
+template <int R, bool ETCH, bool MASKED, int NF = 0, bool FRESH = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R, ETCH, NF > 0)))) void k_stencil_lean(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
                                                                                            const float* __restrict__ quad, const StreamOpts so, const FusedOps F, const FreshTab T) {
+    // NF: how many steps behind the deposit the launch can apply (0: none).  A compile-time number, so that the code and
+    // the scalar registers of steps that cannot be there cost nothing: NF = 1 and 2 for the short tails, FUSE_MAX - 1 for any.
+    constexpr bool FOLD = NF > 0;
+    constexpr int KE = 1 + NF;
+    static_assert(NF >= 0 && NF < FUSE_MAX, "a launch holds FUSE_MAX steps, its own deposit included");
     static_assert(!((FOLD || FRESH) && ETCH), "only deposits take vertical steps along");
     constexpr int NC = 1 << FRESH_MAX_MASKS;
     __shared__ uint32_t s_ftab[FRESH ? (1 + FRESH_MAX_DEP) * NC : 1];       // [0..NC) tops per class, then NC entries per deposit of the run
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
 #pragma unroll
             for (int k = 0; k < FUSE_MAX; k++) {
                 fopen[k] = k < F.n ? 0x01010101u : 0u;
-                if (FIN && k >= 1 && k < F.n && F.masks[k]) fopen[k] = *(const unsigned*)(F.masks[k] + orow + (m_off >> 2));
+                if (FIN && k >= 1 && k < KE && k < F.n && F.masks[k]) fopen[k] = *(const unsigned*)(F.masks[k] + orow + (m_off >> 2));
             }
         }
         // ---- D[du] = op over dv of (p[dv] + a(du, dv)); row dv of the (symmetric) table lists the du's
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
 #pragma unroll
                     for (int c = 0; c < 4; c++) pushed[k][c] = (k == 0 && ((push >> c) & 1)) ? tv[c] : 0u;
                 }
-                fused_steps<1>(g, F, orow + (m_off >> 2), fopen, r4, pushed);
+                fused_steps<1, KE>(g, F, orow + (m_off >> 2), fopen, r4, pushed);
                 nv[0] = r4[0]; nv[1] = r4[1]; nv[2] = r4[2]; nv[3] = r4[3];
             }
             {
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
                 st_rec4((uint32_t*)(m_right ? sink : (char*)(g.top_w + orow) + m_off), nv);
             }
             if (!m_right) {
-                if constexpr (FOLD) fused_store_planes<1>(g, F, orow + (m_off >> 2), pushed);
+                if constexpr (FOLD) fused_store_planes<1, KE>(g, F, orow + (m_off >> 2), pushed);
                 if constexpr (FRESH) {                          // what the deposits of the run in front pushed (as k_vertical_fresh stores it)
                     for (int d = 0; d < T.ndep; d++) {
                         u32x4 pv;

@@ -55,7 +55,8 @@ def parse(k):
     args = [a.strip() for a in m.group(2).split(",")]
     kind = m.group(1)
     if kind in ("stencil_stream", "stencil_lean"):   # <R, ETCH, ...>: never keep statistics
-        if kind == "stencil_lean" and "true" in args[3:5]:      # FOLD / FRESH: the vertical steps behind / in front of a deposit inside its launch
+        # <R, ETCH, MASKED, NF, FRESH>: NF > 0 / FRESH = the vertical steps behind / in front of a deposit inside its launch
+        if kind == "stencil_lean" and (args[3] not in ("0", "false") or (len(args) > 4 and args[4] == "true")):
             return "k_stencil<deposit+vertical>", False
         return "k_stencil<%s>" % ("etch" if args[1] == "true" else "deposit"), False
     if kind == "stencil_sym":             # <R, TJS, ETCH, STATS>
