@@ -353,6 +353,7 @@ def main():
         fused_steps = sum(len(st) for grp, st in launches if grp == "k_vertical_fused")
         folded_launches = sum(1 for grp, st in launches if grp == FOLDED)
         folded_steps = sum(len(st) - 1 for grp, st in launches if grp == FOLDED)
+        schedule = "fold" if folding else ("fuse" if fusing else "single")       # which steps share a launch
         kernels = {}
         for name, (ms, cnt) in prof.items():
             kernels[name] = {"ms_total": round(ms, 4), "launches": cnt, "ms_avg": round(ms / cnt, 4)}
@@ -379,7 +380,9 @@ def main():
         if dom and tpath and os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            same_workload = tj.get("n") == args.n and tj.get("flow") == args.flow and tj.get("n_gpus", 1) == world
+            # (the bytes of a group's launch depend on which steps go out together: same queueing rules only)
+            same_workload = (tj.get("n") == args.n and tj.get("flow") == args.flow and tj.get("n_gpus", 1) == world
+                             and tj.get("schedule", schedule) == schedule)
             if same_workload:
                 tk = tj.get("kernels", {})
                 for name, v in kernels.items():
@@ -445,6 +448,7 @@ def main():
                        "note": "runs of consecutive vertical steps are applied in one pass over the columns: in a launch of their own "
                                "(k_vertical_fused) or inside the lateral deposit in front of or behind them (k_stencil<deposit+vertical>); "
                                "CG_NO_FOLD=1 keeps them out of the lateral launches, CG_NO_FUSE=1 launches every step on its own"},
+            "schedule": schedule,
             "checksum": "%016x" % check,
             "roofline": roofline, "kernels": kernels,
         }

@@ -110,6 +110,7 @@ for lb, v in tr.items():
 if res:
     with open(os.path.join(out, "traffic.json"), "w") as f:
         json.dump({"n": bench_line.get("n"), "flow": bench_line.get("flow"), "n_gpus": bench_line.get("n_gpus", 1),
+                   "schedule": bench_line.get("schedule"),
                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over python3 bench.py --no-cpu; counters are KiB; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B; checked on the vertical deposits, which read the 4-byte top of every column: 1.074 GB expected at 16384^2)",
                    "kernels": res}, f, indent=1)
     print("== HBM traffic per launch (bytes)")
