@@ -50,7 +50,7 @@ constexpr int lean_waves(int R, bool etch, bool fold) { return R <= 3 ? ((etch |
 // put together from the run's mask bytes instead of being loaded, and the tile stores what the run's deposits pushed for
 // the rows it owns -- the run never gets a launch of its own, and its tops are never written or read.
 template <int R, bool ETCH, bool MASKED, int NF = 0, bool FRESH = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R, ETCH, NF > 0)))) void k_stencil_lean(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R, ETCH, NF > 1)))) void k_stencil_lean(GridView g, const uint8_t* __restrict__ mask, int matId, double t,
                                                                                            const float* __restrict__ quad, const StreamOpts so, const FusedOps F, const FreshTab T) {
     // NF: how many steps behind the deposit the launch can apply (0: none).  A compile-time number, so that the code and
     // the scalar registers of steps that cannot be there cost nothing: NF = 1 and 2 for the short tails, FUSE_MAX - 1 for any.
