@@ -384,11 +384,7 @@ __device__ __forceinline__ bool depo_group4(const GridView& g, size_t c0, unsign
         // the old tops go into this step's plane as they are -- each carries the link to what is
         // below it -- whatever the column lengths: one dense line per 32 columns
         const size_t b = (size_t)g.P * g.N + c0;
-        if (push == 15u) st_rec4(g.rec + b, tv);
-        else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) if ((push >> j) & 1) g.rec[b + j] = tv[j];
-        }
+        st_rec4(g.rec + b, tv);              // (the plane is this launch's own: a slot no chain names may hold anything, so the group goes out whole)
     }
     if (STATS) n_app += __popc(app);
     st_rec4(g.top_w + c0, nv);
@@ -516,11 +512,7 @@ __device__ __forceinline__ void depo_group4_int(const GridView& g, size_t c0, un
     }
     if (push) {
         const size_t b = (size_t)g.P * g.N + c0;
-        if (push == 15u) st_rec4(g.rec + b, tv);
-        else {
-#pragma unroll
-            for (int j = 0; j < 4; j++) if ((push >> j) & 1) g.rec[b + j] = tv[j];
-        }
+        st_rec4(g.rec + b, tv);              // (the plane is this launch's own: a slot no chain names may hold anything, so the group goes out whole)
     }
     st_rec4(g.top_w + c0, nv);
 }
@@ -1732,11 +1724,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void k_
                 }
                 if (push) {                                     // the old tops go into this step's plane as they are (see depo_group4)
                     const size_t b = (size_t)g.P * g.N + c0;
-                    if (push == 15u) st_rec4(g.rec + b, tv);
-                    else {
-#pragma unroll
-                        for (int c = 0; c < 4; c++) if ((push >> c) & 1) g.rec[b + c] = tv[c];
-                    }
+                    st_rec4(g.rec + b, tv);          // (the group goes out whole, see depo_group4)
                 }
                 st_rec4(g.top_w + c0, nv);
                 stored = true;
