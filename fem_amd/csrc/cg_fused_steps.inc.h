@@ -3,7 +3,8 @@
 //   g (GridView), F (FusedOps), c0 (size_t: first of the 4 columns), open[FUSE_MAX] (mask bytes of step k, non-zero byte =
 //   open), r[4] (the tops, in and out), pushed[FUSE_MAX][4] (what deposit k pushed into its plane, 0 = nothing; filled in
 //   by the includer for the steps before KB), and the macros CG_FS_KB = first step to apply, CG_FS_KE = one past the last
-//   (compile-time numbers: the steps outside them cost nothing).
+//   (compile-time numbers: the steps outside them cost nothing), and below_mem(g, c0, want, r, b): the intervals below the
+//   records r[] of the columns in `want` that no deposit of the run holds (BelowFromMemory, or a form that knows more).
 // CG_FS_PART 1: steps CG_FS_KB .. F.n-1.   CG_FS_PART 2: the stores of what deposits CG_FS_KB .. F.n-1 pushed.
 #if CG_FS_PART == 1
 #define CG_ON(w, j) (((w) & (0xffu << (8 * (j)))) != 0u)
@@ -60,7 +61,7 @@
             b[j] = bj;
             if ((((act >> j) & 1) != 0) & (p != LNK_NONE) & !inreg) mem |= 1u << j;
         }
-        if (mem) load_below4(g, c0, mem, r, b);
+        if (mem) below_mem(g, c0, mem, r, b);
         double rem[4] = {op.t, op.t, op.t, op.t};
         if (op.vo.etch_kc >= 0) {
             unsigned general = 0, holes = 0;
@@ -79,7 +80,7 @@
                 for (int j = 0; j < 4; j++) {
                     if (!((holes >> j) & 1)) continue;
                     if (rec_lnk(r[j]) == LNK_NONE) r[j] = 0u;
-                    else { uint32_t bb[4] = {0, 0, 0, 0}; fused_below4(g, F, k, c0, 1u << j, r, pushed, bb); r[j] = bb[j]; }
+                    else { uint32_t bb[4] = {0, 0, 0, 0}; fused_below4(g, F, k, c0, 1u << j, r, pushed, bb, below_mem); r[j] = bb[j]; }
                 }
             }
             act = general;
@@ -87,7 +88,7 @@
         if (!(op.t > CG_EPS)) act = 0;                     // cg1:565: nothing to take
         bool have = true;                                  // b[] holds the intervals below the columns in act
         while (act) {
-            if (!have) fused_below4(g, F, k, c0, act, r, pushed, b);
+            if (!have) fused_below4(g, F, k, c0, act, r, pushed, b, below_mem);
             have = false;
             unsigned next = 0;
 #pragma unroll
@@ -100,7 +101,7 @@
                 r[j] = below;
                 if (rec_hole(r[j])) {                              // a gap under the removed layer goes with it
                     if (rec_lnk(r[j]) == LNK_NONE) { r[j] = 0u; continue; }
-                    uint32_t bb[4] = {0, 0, 0, 0}; fused_below4(g, F, k, c0, 1u << j, r, pushed, bb); r[j] = bb[j];
+                    uint32_t bb[4] = {0, 0, 0, 0}; fused_below4(g, F, k, c0, 1u << j, r, pushed, bb, below_mem); r[j] = bb[j];
                 }
                 if (r[j] != 0 && rem[j] > CG_EPS && (isAll || rec_mat(r[j]) == matId)) next |= 1u << j;
             }

@@ -621,8 +621,14 @@ struct FusedOps { FusedOp op[FUSE_MAX]; const uint8_t* masks[FUSE_MAX]; int n, f
 
 // The intervals below the tops r[] of the columns in `want`: from the registers of the run's deposits before step k
 // where the link names one of their planes, else from memory.
+struct BelowFromMemory {
+    __device__ __forceinline__ void operator()(const GridView& g, const size_t c0, const unsigned want, const uint32_t (&r)[4], uint32_t (&b)[4]) const {
+        load_below4(g, c0, want, r, b);
+    }
+};
+template <class BM>
 __device__ __forceinline__ void fused_below4(const GridView& g, const FusedOps& F, const int k, const size_t c0, const unsigned want,
-                                             const uint32_t (&r)[4], const uint32_t (&pushed)[FUSE_MAX][4], uint32_t (&b)[4]) {
+                                             const uint32_t (&r)[4], const uint32_t (&pushed)[FUSE_MAX][4], uint32_t (&b)[4], const BM& below_mem) {
     unsigned mem = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -635,15 +641,15 @@ __device__ __forceinline__ void fused_below4(const GridView& g, const FusedOps& 
             if (q < k && !F.op[q].etch && F.op[q].P == p) { b[j] = pushed[q][j]; found = true; }
         if (!found) mem |= 1u << j;
     }
-    if (mem) load_below4(g, c0, mem, r, b);
+    if (mem) below_mem(g, c0, mem, r, b);
 }
 
 // The body of a run (cg_fused_steps.inc.h) as device functions: the FOLD form of k_stencil_lean calls these, while
 // k_vertical_fused below includes the text -- each of the two is compiled noticeably better its own way.
 // Steps KB .. F.n-1 of the run on the 4 columns at c0.
-template <int KB, int KE = FUSE_MAX>
+template <int KB, int KE = FUSE_MAX, class BM = BelowFromMemory>
 __device__ __forceinline__ void fused_steps(const GridView& g, const FusedOps& F, const size_t c0, const unsigned (&open)[FUSE_MAX], uint32_t (&r)[4],
-                                            uint32_t (&pushed)[FUSE_MAX][4]) {
+                                            uint32_t (&pushed)[FUSE_MAX][4], const BM& below_mem = BM()) {
 #define CG_FS_KB KB
 #define CG_FS_KE KE
 #define CG_FS_PART 1
@@ -695,6 +701,7 @@ __global__ __launch_bounds__(256) void k_vertical_fused(GridView g, const FusedO
         const uint32_t u = k < NUNI ? F.uni_pushed[k] : 0u;
         pushed[k][0] = u; pushed[k][1] = u; pushed[k][2] = u; pushed[k][3] = u;
     }
+    const BelowFromMemory below_mem;
 #define CG_FS_KB NUNI
 #define CG_FS_KE FUSE_MAX
 #define CG_FS_PART 1

@@ -36,7 +36,25 @@ __device__ __forceinline__ bool lean_quant(const StreamOpts& o, float h, unsigne
 }
 
 struct LeanRow { u32x4 a; uint32_t h; unsigned m, mh; };     // a staged row in flight: 4 tops, one halo column's top, their mask bytes
-struct LeanFresh { unsigned m[FRESH_MAX_MASKS], h[FRESH_MAX_MASKS]; };      // FRESH: the bytes of the run's masks at those columns instead of tops
+struct LeanFresh { unsigned m[FRESH_MAX_MASKS], h[FRESH_MAX_MASKS]; };
+
+// FRESH + FOLD: what the run in front of the deposit pushed is stored by this very launch, so a step behind the deposit
+// that digs down to those intervals must not look for them in memory: they come from the class table (tab: the LDS copy,
+// tops first, then one row of classes per deposit of the run; cls: the classes of the lane's 4 columns, 3 bits each).
+struct BelowFromFreshRun {
+    const uint32_t* tab; const int* plane; int ndep; unsigned cls;
+    __device__ __forceinline__ void operator()(const GridView& g, const size_t c0, const unsigned want, const uint32_t (&r)[4], uint32_t (&b)[4]) const {
+        unsigned mem = want;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (!((want >> j) & 1)) continue;
+            const int p = rec_lnk(r[j]);
+            for (int d = 0; d < ndep; d++)
+                if (plane[d] == p) { b[j] = tab[(1 + d) * (1 << FRESH_MAX_MASKS) + ((cls >> (3 * j)) & 7u)]; mem &= ~(1u << j); }
+        }
+        if (mem) load_below4(g, c0, mem, r, b);          // (cannot happen on a grid that was empty before the run; kept for safety)
+    }
+};      // FRESH: the bytes of the run's masks at those columns instead of tops
 
 // Waves per SIMD the register allocation aims at.  Measured at 16384^2: R = 5 at 4 waves spills two registers inside the row
 // loop and is slower than at 3; the etch's update holds more values than the deposit's and spills at 5 waves already at R = 3.
@@ -318,7 +336,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(lean_waves(R
 #pragma unroll
                     for (int c = 0; c < 4; c++) pushed[k][c] = (k == 0 && ((push >> c) & 1)) ? tv[c] : 0u;
                 }
-                fused_steps<1, KE>(g, F, orow + (m_off >> 2), fopen, r4, pushed);
+                if constexpr (FRESH) fused_steps<1, KE>(g, F, orow + (m_off >> 2), fopen, r4, pushed, BelowFromFreshRun{s_ftab, T.plane, T.ndep, fcl});
+                else fused_steps<1, KE>(g, F, orow + (m_off >> 2), fopen, r4, pushed);
                 nv[0] = r4[0]; nv[1] = r4[1]; nv[2] = r4[2]; nv[3] = r4[3];
             }
             {

@@ -774,6 +774,54 @@ def test_runs_of_vertical_steps_in_one_launch(nx, ny, seed, zs):
     _check_runs_of_vertical_steps(nx, ny, seed, zs)
 
 
+@pytest.mark.parametrize("nx,ny,seed", [(96, 160, 21), (128, 256, 22), (70, 324, 23), (64, 516, 24), (200, 68, 25), (33, 260, 26), (150, 512, 27), (90, 324, 28)])
+def test_vertical_steps_inside_lateral_deposits(nx, ny, seed):
+    """A lateral deposit on an undivided grid waits for the vertical steps behind it and applies them inside its own launch
+    (one, two or up to five of them: three instantiations), and a deposit without a mask that finds the queue of a reset grid
+    waiting takes that run along too.  Seeded cases of both: radii 1..6 (5 and 6 take no steps behind them), lateral deposits
+    with and without a mask, 0..7 vertical steps behind (more than five: the rest goes out as a run of its own), etches in
+    the tail that remove what the deposit has just laid down and go on into older layers, strips whose last lanes lie beyond
+    the grid (ny not a multiple of 256).  The state is compared with the oracle only after each case, so the steps of a case
+    really go out together."""
+    fem = _engine()
+    rng = _lcg(seed)
+    L = 2 * max(nx, ny)
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    reds = [fem.reduce_mask(_random_mask_data(rng, L, 7)) for _ in range(3)]
+    masks = [(g.mask_from_shapes(r), o.mask_raster(r)) for r in reds]
+    ts = [0.05, 1.0, 2.5, 4, 6, 7.25, 8, 10, 13.05, 21]
+    def both(fn, mi, *a):
+        gm, om = (None, None) if mi is None else masks[mi]
+        getattr(g, fn)(gm, *a); getattr(o, fn)(om, *a)
+    def tail(n):
+        for _ in range(n):
+            kind = "deposit_general" if next(rng) % 5 < 2 else "etch_general"
+            mi = next(rng) % 4
+            mat = [3, 4, 5, 6, 255][next(rng) % (5 if kind == "etch_general" else 4)]
+            both(kind, mi if mi < 3 else None, mat, ts[next(rng) % len(ts)], 0)
+    for case in range(18):
+        fresh = case % 3 == 0
+        if fresh:                                              # a run on the reset grid in front of the deposit
+            g.createNewGrid(); o.reset()
+            both("deposit_general", None, 3, 30, 0)
+            for k in range(next(rng) % 5):
+                mi = next(rng) % 4
+                both("deposit_general" if k % 2 == 0 else "etch_general", mi if mi < 3 else None, 4 + k % 2 if k % 2 == 0 else 255, ts[next(rng) % len(ts)], 0)
+        R = 1 + next(rng) % 6
+        S = [1.0, 0.5][next(rng) % 2]
+        t = 2.0 * R / S - 0.5                                  # t*S just under R cells of 2 nm: radius R
+        mi = None if (fresh or next(rng) % 3) else next(rng) % 3
+        both("deposit_general", mi, 3 + next(rng) % 4, t, S)
+        n = [0, 1, 1, 2, 2, 3, 5, 7][next(rng) % 8]
+        if case % 5 == 4:                                      # an etch that takes the new layer off again and goes on below it
+            both("etch_general", next(rng) % 3, 255, t + 3.0, 0); n = max(0, n - 1)
+        tail(n)
+        assert g.checksum() == o.checksum(), f"case {case}: R={R} S={S} mask={mi} fresh={fresh} tail={n}"
+    _assert_same(g, o.arrays(), "after the cases")
+    g.close()
+
+
 def _check_runs_of_vertical_steps(nx, ny, seed, zs=0.1):
     """Consecutive vertical steps are queued and applied in one pass over the columns (k_vertical_fused) when something
     else looks at the grid.  Seeded runs of 1..9 vertical steps (the queue holds 6) with and without masks, thicknesses
