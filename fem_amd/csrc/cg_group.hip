@@ -70,6 +70,7 @@ struct cg_group {
     double dx = 0, dy = 0, zs = 0.1;
     std::vector<cg_grid*> s;
     std::vector<int> dev, i0, nxl;
+    std::vector<hipStream_t> st;                   // every slab's own stream
     std::vector<hipStream_t> xfer;                 // one transfer stream per slab
     std::vector<hipEvent_t> packed, arrived, taken;   // per slab: its send rows are written / its received rows are in / its send rows have been read
     std::vector<GMask> masks;
@@ -103,7 +104,9 @@ int from_slab(cg_group* G, int k, int rc) {
 
 double js_round(double x) { double r = std::floor(x); if (x - r >= 0.5) r += 1.0; return r; }
 
-hipStream_t slab_stream(cg_group* G, int k) { void* p = nullptr; (void)cg_get_stream(G->s[k], &p); return (hipStream_t)p; }
+// (the stream a slab was made with: the group owns its slabs and never re-binds them, and asking the slab itself would
+// launch the vertical steps it holds back for one fused launch)
+hipStream_t slab_stream(cg_group* G, int k) { return G->st[k]; }
 
 int ensure_bufs(cg_group* G, std::vector<Bufs>& set, size_t bytes) {
     for (int k = 0; k < G->n; k++) {
@@ -331,7 +334,7 @@ int cg_group_create(int nx_global, int ny, double dx, double dy, int lmax_init, 
     cg_group* G = new cg_group();
     G->n = nslabs; G->nx_global = nx_global; G->ny = ny; G->dx = dx; G->dy = dy; G->zs = zscale;
     G->s.assign(nslabs, nullptr); G->dev.assign(devices, devices + nslabs); G->i0.resize(nslabs); G->nxl.resize(nslabs);
-    G->xfer.assign(nslabs, nullptr); G->packed.assign(nslabs, nullptr); G->arrived.assign(nslabs, nullptr); G->taken.assign(nslabs, nullptr);
+    G->st.assign(nslabs, nullptr); G->xfer.assign(nslabs, nullptr); G->packed.assign(nslabs, nullptr); G->arrived.assign(nslabs, nullptr); G->taken.assign(nslabs, nullptr);
     G->ghost.resize(nslabs); G->seedbuf.resize(nslabs);
     auto body = [&]() -> int {
         // rows are dealt out as evenly as whole rows allow, the first slabs taking the extra ones
@@ -341,6 +344,7 @@ int cg_group_create(int nx_global, int ny, double dx, double dy, int lmax_init, 
             GHIP(G, hipSetDevice(G->dev[k]));
             int rc = cg_create_slab(nx_global, ny, G->i0[k], G->nxl[k], dx, dy, lmax_init, zscale, &G->s[k]);
             if (rc) return gfail(G, rc, "slab %d on device %d: %s", k, G->dev[k], cg_last_error(nullptr));
+            { void* p = nullptr; SLAB(G, k, cg_get_stream(G->s[k], &p)); G->st[k] = (hipStream_t)p; }
             GHIP(G, hipStreamCreateWithFlags(&G->xfer[k], hipStreamNonBlocking));
             GHIP(G, hipEventCreateWithFlags(&G->packed[k], hipEventDisableTiming));
             GHIP(G, hipEventCreateWithFlags(&G->arrived[k], hipEventDisableTiming));
