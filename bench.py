@@ -296,10 +296,11 @@ def main():
         # cross-sections of C5, the end of the timed region.  The same rule here says which launch a step's bytes belong to.
         FUSE_MAX = 6
         fusing = not os.environ.get("CG_NO_FUSE")
-        # A lateral deposit on an undivided grid takes vertical steps along inside its own launch (k_stencil_lean): up to
-        # FUSE_MAX - 1 that follow it when its radius is <= 4 (FOLD form), and, without a mask, the run that was waiting on
-        # the reset grid in front of it (FRESH form).
-        folding = fusing and world == 1 and not os.environ.get("CG_NO_FOLD") and not slice_idx
+        # A lateral deposit takes vertical steps along inside its own launch (k_stencil_lean): up to FUSE_MAX - 1 that follow
+        # it when its radius is <= 4 (FOLD form), and, on an undivided grid and without a mask, the run that was waiting on
+        # the reset grid in front of it (FRESH form).  On a slab the launch covers the rows that read no neighbour's
+        # message; the rows that do get the deposit from the general kernel and the steps from fused launches of their own.
+        folding = fusing and not os.environ.get("CG_NO_FOLD") and not slice_idx
         FOLDED = "k_stencil<deposit+vertical>"
         launches, cur = [], None              # (kernel group, [step indices]); cur = a launch that may still take steps: [kind, steps, room]
 
@@ -331,7 +332,7 @@ def main():
             else:
                 s_ = flow[idx]
                 small = math.ceil(max(0.0, s_["t"]) * max(0.0, min(1.0, s_["S"])) / 2.0) <= 4
-                if folding and kd == "k_stencil<deposit>" and cur and cur[0] == "run" and cur[1][0] == 0 and s_["mask"] is None:
+                if folding and world == 1 and kd == "k_stencil<deposit>" and cur and cur[0] == "run" and cur[1][0] == 0 and s_["mask"] is None:
                     cur = ["lat", cur[1] + [idx], FUSE_MAX - 1 if small else 0]
                     if cur[2] == 0:
                         close()
@@ -354,13 +355,25 @@ def main():
         folded_launches = sum(1 for grp, st in launches if grp == FOLDED)
         folded_steps = sum(len(st) - 1 for grp, st in launches if grp == FOLDED)
         schedule = "fold" if folding else ("fuse" if fusing else "single")       # which steps share a launch
+        # timed scopes the library opens per launch of the list above: one on an undivided grid; on a slab a lateral
+        # step has two (the rows that read no message, the rows that do) and a deposit with steps inside has its own, a
+        # plain deposit scope for the edge rows and a fused launch per edge band for the steps there (rank 0: one band)
+        expected = {}
+        for grp, _ in launches:
+            if world > 1 and grp in ("k_stencil<etch>", "k_stencil<deposit>"):
+                expected[grp] = expected.get(grp, 0) + 2
+            elif world > 1 and grp == FOLDED:
+                for nm in (FOLDED, "k_stencil<deposit>", "k_vertical_fused"):
+                    expected[nm] = expected.get(nm, 0) + 1
+            else:
+                expected[grp] = expected.get(grp, 0) + 1
         kernels = {}
         for name, (ms, cnt) in prof.items():
             kernels[name] = {"ms_total": round(ms, 4), "launches": cnt, "ms_avg": round(ms / cnt, 4)}
             if name in kbytes and ms > 0:
                 kernels[name]["algorithmic_GB"] = round(kbytes[name] / 1e9, 3)
                 kernels[name]["GBps"] = round(kbytes[name] / 1e9 / (ms / 1e3), 1)
-                expect = sum(1 for grp, _ in launches if grp == name)
+                expect = expected.get(name, 0)
                 if expect != cnt:                           # the rule above and the library disagree on what went out together
                     kernels[name]["launches_by_bench_rule"] = expect
                 if kbytes_steps[name] != kbytes[name]:      # what the same steps move when every one is a pass of its own

@@ -102,6 +102,7 @@ struct Pending {
     ConfKernel* K = nullptr;
     bool has_lower = false, has_upper = false;
     bool interior_done = false, may_overflow = false; int P = -1;     // set by cg_stencil_interior
+    bool held = false;          // cg_stencil_interior launched nothing: the deposit will wait for the steps behind it (cg_stencil_finish)
 };
 
 }  // namespace
@@ -174,6 +175,7 @@ struct cg_grid {
     // pre: the run of vertical steps that was waiting on the reset grid when the deposit came (applied in the same launch,
     // k_stencil_lean's FRESH form).
     struct LatPending { bool active = false; const uint8_t* mask = nullptr; int mat = 0; double t_eff = 0; int R = 0; ConfKernel* K = nullptr; int P = -1;
+                        const uint8_t* halo_lo = nullptr; const uint8_t* halo_up = nullptr;      // a slab's deposit: the neighbours' rows it received
                         std::vector<VQOp> pre; } lat;
     std::vector<VQOp> vq;
     bool fuse = true;                                      // CG_NO_FUSE=1: every vertical step is launched on its own
@@ -763,9 +765,20 @@ int launch_stencil(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t
         sopt.sink = g->d_sink;
         sopt.fast_rows = (etch && !K->quad.empty() && K->quad[0] != -INFINITY && !getenv("CG_STREAM_NOFAST")) ? 1 : 0;
         StreamArgs sa{gv, mask, mat, t_eff, R, halo_lo, halo_up, K->d_quad, sopt, g->d_flags, g->d_stats, lean, fold, fresh};
+        // The rows that read a message are few (a tile row or two per slab edge) and a wave walks its tile row by row:
+        // in tiles as tall as the others' that launch would last as long as one whole tile takes, on a nearly empty
+        // device.  It is cut into tiles of edge_ti rows instead (env CG_EDGE_TI; more waves, each with fewer rows).
+        static const int edge_ti_env = [] { const char* e = getenv("CG_EDGE_TI"); const int v = e ? atoi(e) : 8; return (v >= 4 && v <= 256) ? v : 8; }();
+        const int edge_ti = (ti % edge_ti_env == 0) ? edge_ti_env : ti;
         const auto go = [&](const Band& band, bool msg) {
-            sa.gv.tile_i0 = band.t0; sa.gv.tile_in = band.n; sa.gv.sup_i = 1; sa.gv.sup_j = 1;
-            launch_stream(K->Re, etch, msg, mask != nullptr, (unsigned)(((long)band.n * tiles_j + 7) / 8 * 8), g->stream, sa);
+            int t0 = band.t0, n = band.n;
+            sa.gv.ti = ti;
+            if (msg && edge_ti != ti) {
+                const int r0 = band.t0 * ti, r1 = std::min(g->nx, (band.t0 + band.n) * ti);
+                t0 = r0 / edge_ti; n = (r1 - r0 + edge_ti - 1) / edge_ti; sa.gv.ti = edge_ti;
+            }
+            sa.gv.tile_i0 = t0; sa.gv.tile_in = n; sa.gv.sup_i = 1; sa.gv.sup_j = 1;
+            launch_stream(K->Re, etch, msg, mask != nullptr, (unsigned)(((long)n * tiles_j + 7) / 8 * 8), g->stream, sa);
         };
         if (part != PART_BOUNDARY) for (int b_ = 0; b_ < n_int; b_++) go(bi[b_], false);
         if (part != PART_INTERIOR) for (int b_ = 0; b_ < n_bnd; b_++) go(bb[b_], true);
@@ -1174,6 +1187,69 @@ bool fresh_run(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, int* rc) {
     return true;
 }
 
+// One k_vertical_fused launch for `ops` (2..FUSE_MAX of them, or 1 on a range) over the columns [off, off + count): the
+// whole grid, or whole rows of it whose count is a multiple of the 1024 columns a workgroup takes (the kernel then sees
+// a grid that begins at `off`; its plane stride stays N).
+int launch_fused(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, size_t off, size_t count) {
+    const bool whole = off == 0 && count == g->N;
+    FusedOps F = {};
+    F.n = (int)ops.size(); F.fresh = (whole && ops[0].fresh) ? 1 : 0;
+    for (int k = 0; k < F.n; k++) {
+        const cg_grid::VQOp& o = ops[k];
+        F.op[k].t = o.t; F.op[k].vo = vert_opts(g, o.t, o.etch);
+        F.op[k].etch = o.etch ? 1 : 0; F.op[k].mat = o.mat; F.op[k].P = o.P;
+        F.masks[k] = o.mask ? o.mask + off : nullptr;
+    }
+    F.rt_shift = -1;
+    if ((g->ny >> 2) % 256 == 0) {
+        const unsigned rt = (unsigned)((g->ny >> 2) / 256);
+        if (rt > 1 && (rt & (rt - 1)) == 0) F.rt_shift = __builtin_ctz(rt);
+    }
+    if (F.fresh) {
+        // The leading deposits without a mask leave every column of the reset grid the same: _depoAtTop_ (cg1:397-426)
+        // on that one column here, with the quantiser in its literal form (which the device's forms equal by construction).
+        uint32_t top = 0;
+        const auto z1 = [](uint32_t r) { return r & 0xffffu; };
+        const auto make = [](uint32_t q, int mat, int lnk) { return (q & 0xffffu) | ((uint32_t)(mat & 255) << 16) | REC_LAYER | ((uint32_t)lnk << LNK_SHIFT); };
+        int k = 0;
+        for (; k < F.n && k < FUSE_UNI_MAX && !ops[k].etch && !ops[k].mask; k++) {
+            const uint32_t q = quantz_host((double)z1(top) * g->zscale + ops[k].t, g->zscale);
+            F.uni_pushed[k] = 0;
+            if (top != 0 && (int)((top >> 16) & 255u) == ops[k].mat) top = (top & 0xffff0000u) | q;
+            else { F.uni_pushed[k] = top; top = make(q, ops[k].mat, top != 0 ? ops[k].P : LNK_NONE); }
+        }
+        F.nuni = k; F.uni_top = top;
+    }
+    GridView gv = view(g);
+    if (!whole) {
+        if (count % 1024 != 0 || off % 4 != 0 || off + count > g->N) return fail(g, CG_ERR_STATE, "a run of vertical steps over columns %zu + %zu", off, count);
+        gv.top += off; gv.top_w += off; gv.rec += off;
+    }
+    const size_t nb = whole ? (g->N / 4 + 255) / 256 : count / 1024;
+    ProfScope ps(g, CG_K_VERTICAL_FUSED);
+    const dim3 gridF((unsigned)std::max<size_t>(1, nb));
+    switch (F.nuni) {
+    case 0: hipLaunchKernelGGL(k_vertical_fused<0>, gridF, dim3(256), 0, g->stream, gv, F); break;
+    case 1: hipLaunchKernelGGL(k_vertical_fused<1>, gridF, dim3(256), 0, g->stream, gv, F); break;
+    case 2: hipLaunchKernelGGL(k_vertical_fused<2>, gridF, dim3(256), 0, g->stream, gv, F); break;
+    default: hipLaunchKernelGGL(k_vertical_fused<3>, gridF, dim3(256), 0, g->stream, gv, F); break;
+    }
+    HIPCHK(g, hipGetLastError());
+    return CG_OK;
+}
+
+// The rows of a slab whose lateral step reads a neighbour's message, as ranges of columns: [off, off + count) each.
+int boundary_column_ranges(const cg_grid* g, const ConfKernel* K, int R, bool lower, bool upper, size_t off[2], size_t count[2]) {
+    Band bb[2];
+    const int ti = stream_tile_rows(K->Re);
+    const int n = stencil_bands(g->nx, ti, R, lower, upper, 2 /* PART_BOUNDARY */, bb);
+    for (int b = 0; b < n; b++) {
+        const int r0 = bb[b].t0 * ti, r1 = std::min(g->nx, (bb[b].t0 + bb[b].n) * ti);
+        off[b] = (size_t)r0 * g->ny; count[b] = (size_t)(r1 - r0) * g->ny;
+    }
+    return n;
+}
+
 int flush_vertical(cg_grid* g) {
     if (g->lat.active) {
         // the waiting lateral deposit, with the vertical steps queued behind it inside its launch when there are any
@@ -1196,11 +1272,28 @@ int flush_vertical(cg_grid* g) {
         FreshTab T;
         const bool pre = !L.pre.empty();
         if (pre && !fresh_table(g, L.pre, T)) return fail(g, CG_ERR_STATE, "the waiting run of vertical steps no longer fits the table form");
-        int rc = launch_stencil(g, false, L.mask, L.mat, L.t_eff, L.R, L.K, -1, nullptr, nullptr, L.P, 0 /* PART_ALL */, false, fold ? &F : nullptr, pre ? &T : nullptr);
-        if (rc) return rc;
-        std::swap(g->top, g->top_alt);
-        if (fold) return CG_OK;
-        g->vq.swap(behind);
+        if (L.halo_lo || L.halo_up) {
+            // a slab: the steps behind go out inside the launch over the rows that read no message; the other rows get
+            // the deposit from the kernel that reads the messages and then the steps in a pass of their own
+            int rc = launch_stencil(g, false, L.mask, L.mat, L.t_eff, L.R, L.K, -1, L.halo_lo, L.halo_up, L.P, 1 /* PART_INTERIOR */, false, fold ? &F : nullptr, nullptr);
+            if (rc) return rc;
+            rc = launch_stencil(g, false, L.mask, L.mat, L.t_eff, L.R, L.K, -1, L.halo_lo, L.halo_up, L.P, 2 /* PART_BOUNDARY */, false, nullptr, nullptr);
+            if (rc) return rc;
+            std::swap(g->top, g->top_alt);
+            if (fold) {
+                size_t off[2], count[2];
+                const int nr = boundary_column_ranges(g, L.K, L.R, L.halo_lo != nullptr, L.halo_up != nullptr, off, count);
+                for (int b = 0; b < nr; b++) { rc = launch_fused(g, behind, off[b], count[b]); if (rc) return rc; }
+                return CG_OK;
+            }
+            g->vq.swap(behind);
+        } else {
+            int rc = launch_stencil(g, false, L.mask, L.mat, L.t_eff, L.R, L.K, -1, nullptr, nullptr, L.P, 0 /* PART_ALL */, false, fold ? &F : nullptr, pre ? &T : nullptr);
+            if (rc) return rc;
+            std::swap(g->top, g->top_alt);
+            if (fold) return CG_OK;
+            g->vq.swap(behind);
+        }
     }
     if (g->vq.empty()) return CG_OK;
     std::vector<cg_grid::VQOp> ops; ops.swap(g->vq);
@@ -1225,45 +1318,7 @@ int flush_vertical(cg_grid* g) {
         }
         return CG_OK;
     }
-    FusedOps F = {};
-    F.n = (int)ops.size(); F.fresh = ops[0].fresh ? 1 : 0;
-    for (int k = 0; k < F.n; k++) {
-        const cg_grid::VQOp& o = ops[k];
-        F.op[k].t = o.t; F.op[k].vo = vert_opts(g, o.t, o.etch);
-        F.op[k].etch = o.etch ? 1 : 0; F.op[k].mat = o.mat; F.op[k].P = o.P;
-        F.masks[k] = o.mask;
-    }
-    F.rt_shift = -1;
-    if ((g->ny >> 2) % 256 == 0) {
-        const unsigned rt = (unsigned)((g->ny >> 2) / 256);
-        if (rt > 1 && (rt & (rt - 1)) == 0) F.rt_shift = __builtin_ctz(rt);
-    }
-    if (F.fresh) {
-        // The leading deposits without a mask leave every column of the reset grid the same: _depoAtTop_ (cg1:397-426)
-        // on that one column here, with the quantiser in its literal form (which the device's forms equal by construction).
-        uint32_t top = 0;
-        const auto z1 = [](uint32_t r) { return r & 0xffffu; };
-        const auto make = [](uint32_t q, int mat, int lnk) { return (q & 0xffffu) | ((uint32_t)(mat & 255) << 16) | REC_LAYER | ((uint32_t)lnk << LNK_SHIFT); };
-        int k = 0;
-        for (; k < F.n && k < FUSE_UNI_MAX && !ops[k].etch && !ops[k].mask; k++) {
-            const uint32_t q = quantz_host((double)z1(top) * g->zscale + ops[k].t, g->zscale);
-            F.uni_pushed[k] = 0;
-            if (top != 0 && (int)((top >> 16) & 255u) == ops[k].mat) top = (top & 0xffff0000u) | q;
-            else { F.uni_pushed[k] = top; top = make(q, ops[k].mat, top != 0 ? ops[k].P : LNK_NONE); }
-        }
-        F.nuni = k; F.uni_top = top;
-    }
-    const size_t nb = (g->N / 4 + 255) / 256;
-    ProfScope ps(g, CG_K_VERTICAL_FUSED);
-    const dim3 gridF((unsigned)std::max<size_t>(1, nb));
-    switch (F.nuni) {
-    case 0: hipLaunchKernelGGL(k_vertical_fused<0>, gridF, dim3(256), 0, g->stream, view(g), F); break;
-    case 1: hipLaunchKernelGGL(k_vertical_fused<1>, gridF, dim3(256), 0, g->stream, view(g), F); break;
-    case 2: hipLaunchKernelGGL(k_vertical_fused<2>, gridF, dim3(256), 0, g->stream, view(g), F); break;
-    default: hipLaunchKernelGGL(k_vertical_fused<3>, gridF, dim3(256), 0, g->stream, view(g), F); break;
-    }
-    HIPCHK(g, hipGetLastError());
-    return CG_OK;
+    return launch_fused(g, ops, 0, g->N);
 }
 
 int enqueue_vertical(cg_grid* g, bool etch, const uint8_t* mask, int mat, double t) {
@@ -1671,7 +1726,7 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     g->pend.active = true; g->pend.kind = kind; g->pend.mask_id = mask_id; g->pend.mat = mat; g->pend.R = R; g->pend.K = K;
     g->pend.t_eff = (kind == CG_STENCIL_DEPOSIT) ? K->baseAdd : t;        // cg1:470/499 vs cg1:702
     g->pend.has_lower = has_lower != 0; g->pend.has_upper = has_upper != 0;
-    g->pend.interior_done = false; g->pend.may_overflow = false; g->pend.P = -1; g->pend.prefold = prefold;
+    g->pend.interior_done = false; g->pend.may_overflow = false; g->pend.P = -1; g->pend.prefold = prefold; g->pend.held = false;
     if (radius_rows) *radius_rows = R;
     return CG_OK;
 }
@@ -1736,6 +1791,27 @@ static int stencil_prepare_deposit(cg_grid* g) {
     return CG_OK;
 }
 
+// Can the open deposit wait for the vertical steps that may follow it (they then go out inside its launch, see
+// flush_vertical)?  slab: the step reads rows of a neighbour.
+static bool deposit_can_wait(cg_grid* g, const Pending& p, bool slab) {
+    static const bool no_fold = getenv("CG_NO_FOLD") != nullptr;
+    if (no_fold || !g->fuse || g->stats_on || !g->split || p.may_overflow || g->N % 4 != 0 || g->has_gaps || g->has_cavity || g->len_bound + 1 > g->lmax_vis)
+        return false;
+    if (!slab) {
+        if (g->nx != g->nx_global || !(p.K->Re <= LEAN_FOLD_MAX_R || (p.prefold && !g->vq.empty()))) return false;
+    } else {
+        if (p.K->Re > LEAN_FOLD_MAX_R || p.prefold) return false;
+        // the rows that read a message take the steps in launches of whole workgroups; the others must exist
+        size_t off[2], count[2];
+        const int nr = boundary_column_ranges(g, p.K, p.R, p.has_lower, p.has_upper, off, count);
+        size_t edge = 0;
+        for (int b = 0; b < nr; b++) { if (count[b] % 1024 != 0 || off[b] % 4 != 0) return false; edge += count[b]; }
+        if (edge >= g->N) return false;
+    }
+    const StencilForm form = stencil_form(g, p.K, false, p.mat, -1, false);
+    return form.streams && form.lean;
+}
+
 int cg_stencil_interior(cg_grid* g) {
     NEED(g);
     if (!g->pend.active) return fail(g, CG_ERR_STATE, "no stencil step is open");
@@ -1746,6 +1822,11 @@ int cg_stencil_interior(cg_grid* g) {
     const bool etch = g->pend.kind == CG_STENCIL_ETCH;
     if (!etch) { int rc = stencil_prepare_deposit(g); if (rc) return rc; }
     const Pending p = g->pend;
+    if (!etch && deposit_can_wait(g, p, true)) {
+        // the deposit will wait for the vertical steps behind it (cg_stencil_finish): nothing goes out yet
+        g->pend.interior_done = true; g->pend.held = true;
+        return CG_OK;
+    }
     const uint8_t* halo_lo = p.has_lower ? g->halo[2] : nullptr;           // not read by interior tiles; they tell the bands
     const uint8_t* halo_up = p.has_upper ? g->halo[3] : nullptr;
     int rc = launch_stencil(g, etch, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, etch ? -1 : p.P, PART_INTERIOR, !etch && p.may_overflow);
@@ -1775,20 +1856,18 @@ int cg_stencil_finish(cg_grid* g) {
         return CG_OK;
     }
 
-    // A deposit that the lean kernel takes on an undivided grid waits for the vertical steps behind it: they go out
-    // inside its launch (flush_vertical).  Only when nothing of what the host tracks needs the device before that.
-    static const bool no_fold = getenv("CG_NO_FOLD") != nullptr;
-    if (!no_fold && g->fuse && !g->stats_on && g->split && part == PART_ALL && !halo_lo && !halo_up && !p.may_overflow && g->nx == g->nx_global &&
-        g->N % 4 == 0 && !g->has_gaps && !g->has_cavity && g->len_bound + 1 <= g->lmax_vis && (p.K->Re <= LEAN_FOLD_MAX_R || (p.prefold && !g->vq.empty()))) {
-        const StencilForm form = stencil_form(g, p.K, false, p.mat, -1, false);
-        if (form.streams && form.lean) {
-            g->lat.pre.clear();
-            if (p.prefold) g->lat.pre.swap(g->vq);             // the waiting run goes with it
-            g->lat.active = true; g->lat.mask = mask; g->lat.mat = p.mat; g->lat.t_eff = p.t_eff; g->lat.R = p.R; g->lat.K = p.K; g->lat.P = p.P;
-            g->len_valid = false;
-            if (g->len_bound < 255) g->len_bound += 1;
-            return CG_OK;
-        }
+    // A deposit that the lean kernel takes waits for the vertical steps behind it: they go out inside its launch
+    // (flush_vertical).  Only when nothing of what the host tracks needs the device before that.  On a slab the rows
+    // that read a neighbour's message get the steps in a pass of their own; the messages stay where they arrived.
+    const bool slab = halo_lo || halo_up;
+    if (p.held || (part == PART_ALL && deposit_can_wait(g, p, slab))) {
+        g->lat.pre.clear();
+        if (p.prefold) g->lat.pre.swap(g->vq);             // the waiting run goes with it
+        g->lat.active = true; g->lat.mask = mask; g->lat.mat = p.mat; g->lat.t_eff = p.t_eff; g->lat.R = p.R; g->lat.K = p.K; g->lat.P = p.P;
+        g->lat.halo_lo = halo_lo; g->lat.halo_up = halo_up;
+        g->len_valid = false;
+        if (g->len_bound < 255) g->len_bound += 1;
+        return CG_OK;
     }
     if (p.prefold) { int rcf = flush_vertical(g); if (rcf) return rcf; rcf = materialize(g); if (rcf) return rcf; }      // not this time: the run first
     int rc = launch_stencil(g, false, mask, p.mat, p.t_eff, p.R, p.K, -1, halo_lo, halo_up, p.P, part, p.may_overflow); if (rc) return rc;

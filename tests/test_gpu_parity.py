@@ -776,6 +776,44 @@ def test_runs_of_vertical_steps_in_one_launch(nx, ny, seed, zs):
 
 @pytest.mark.parametrize("nx,ny,seed", [(96, 160, 21), (128, 256, 22), (70, 324, 23), (64, 516, 24), (200, 68, 25), (33, 260, 26), (150, 512, 27), (90, 324, 28)])
 def test_vertical_steps_inside_lateral_deposits(nx, ny, seed):
+    _check_steps_inside_lateral_deposits(nx, ny, seed, 0)
+
+
+@pytest.mark.parametrize("nx,ny,seed,parts", [(512, 256, 31, 2), (768, 256, 32, 3), (640, 128, 33, 2), (600, 512, 34, 3), (520, 260, 35, 2)])
+def test_vertical_steps_inside_lateral_deposits_on_slabs(nx, ny, seed, parts):
+    """The same on a grid cut into slabs (cg_group_*): a slab's deposit waits as well, the steps behind it go out inside
+    the launch over the rows that read no neighbour's message and in a pass of their own over the rows that do.  Sizes whose
+    slabs have such inner rows (tiles are 64 rows tall) and whose edge bands are whole workgroups of columns; the last size
+    has bands that are not, and takes the launches one by one."""
+    _check_steps_inside_lateral_deposits(nx, ny, seed, parts)
+
+
+def test_a_slabs_deposit_takes_the_steps_behind_it():
+    """What the slab test above relies on, seen from the launch counters: on a slab with a neighbour on either side a
+    lateral deposit followed by two vertical steps goes out as a launch of the deposit-with-steps kind (inner rows), plain
+    deposit launches (the two bands that read messages) and two fused vertical launches (the steps on those bands)."""
+    fem = _engine()
+    n = 256
+    g = fem.ColumnGrid(dx=2.0, dy=2.0, slab=(3 * n, n, n, n))
+    def step(kind, mat, t, S):
+        R = g.stencil_begin(kind, None, mat, t, S, 1, 1)
+        if R:
+            g.stencil_interior(); g.stencil_finish()
+    step(0, 3, 30, 0)               # (0: deposit, 1: etch)
+    g.sync()
+    g.profile(True)
+    step(0, 4, 7.5, 1.0)            # radius 4
+    step(0, 5, 3.0, 0)
+    step(1, 255, 1.0, 0)
+    g.sync()
+    prof = g.profile(False)
+    assert prof.get("k_stencil<deposit+vertical>", (0, 0))[1] == 1, prof
+    assert prof.get("k_stencil<deposit>", (0, 0))[1] == 1, prof             # (one timed scope around the two bands' launches)
+    assert prof.get("k_vertical_fused", (0, 0))[1] == 2, prof
+    g.close()
+
+
+def _check_steps_inside_lateral_deposits(nx, ny, seed, parts):
     """A lateral deposit on an undivided grid waits for the vertical steps behind it and applies them inside its own launch
     (one, two or up to five of them: three instantiations), and a deposit without a mask that finds the queue of a reset grid
     waiting takes that run along too.  Seeded cases of both: radii 1..6 (5 and 6 take no steps behind them), lateral deposits
@@ -786,7 +824,7 @@ def test_vertical_steps_inside_lateral_deposits(nx, ny, seed):
     fem = _engine()
     rng = _lcg(seed)
     L = 2 * max(nx, ny)
-    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    g = fem.GroupGrid(2 * nx, 2 * ny, 2, 2, devices=[0] * parts) if parts else fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
     o = OracleGrid(2 * nx, 2 * ny, 2, 2)
     reds = [fem.reduce_mask(_random_mask_data(rng, L, 7)) for _ in range(3)]
     masks = [(g.mask_from_shapes(r), o.mask_raster(r)) for r in reds]
