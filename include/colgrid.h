@@ -20,8 +20,9 @@
  * Vertical steps (cg_deposit_general / cg_etch_general / cg_stencil_begin with t*S < min(dx, dy))
  * are queued in the handle, up to six (sixteen on a grid that has just been reset), and launched
  * together by the next entry point that is not such a step (cg_sync included): same results, one
- * pass over the columns instead of one per step.  A lateral deposit on an undivided grid may wait in
- * the same way for the vertical steps that follow it (up to five), which then run inside its launch.
+ * pass over the columns instead of one per step.  A lateral deposit (on an undivided grid or on a slab)
+ * may wait in the same way for the vertical steps that follow it (up to five), which then run inside
+ * its launch.
  * Consequences for a caller that brings its own stream (cg_set_stream): when such a call returns,
  * nothing of it may be on the stream yet -- an event recorded, or dependent work enqueued, right
  * after it does not wait for the step.  cg_sync, cg_get_stream or any entry point other than a
@@ -321,6 +322,11 @@ int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q);
  *                        halo message, so the exchange overlaps with them;
  *   cg_stencil_finish -> dilation / erosion and the per-column update (of the rows
  *                        cg_stencil_interior has not done).
+ * A deposit that waits for the vertical steps behind it (see the top of this file) launches nothing
+ * in cg_stencil_interior nor in cg_stencil_finish: both parts go out with the queued steps, and the
+ * received halo rows are read then -- they must stay untouched until the handle's next call that is
+ * not a vertical step (the next cg_stencil_begin of a lateral step packs only after it has launched
+ * them, so a driver that exchanges after every cg_stencil_begin needs no extra care).
  * has_lower / has_upper = 0 means domain edge: heights are clamp-replicated and flags are
  * zero there (cg1:373-387, 671).
  */
