@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1558,12 +1559,19 @@ int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const d
         if (shapes[s].type == CG_SHAPE_POLYGON && (shapes[s].pt_off < 0 || shapes[s].pt_cnt < 0 || shapes[s].pt_off + shapes[s].pt_cnt > npts))
             return fail(g, CG_ERR_ARG, "shape %d: polygon points [%d,+%d) outside the %d given", s, shapes[s].pt_off, shapes[s].pt_cnt, npts);
     static_assert(sizeof(Shape) == sizeof(cg_shape), "Shape mirrors cg_shape");
+    static const bool tm_on = getenv("CG_MASK_TIMING") != nullptr;
+    auto tm_now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tm0 = tm_now();
+    auto tm = [&](const char* what) { if (!tm_on) return; (void)hipStreamSynchronize(g->stream); const double t1 = tm_now(); fprintf(stderr, "  [mask] %-18s %.3f ms\n", what, t1 - tm0); tm0 = t1; };
+    tm("check");
     uint8_t* buf; int rc = new_mask_slot(g, &buf, mask_id); if (rc) return rc;
+    tm("raster alloc");
     Shape* d_sh = nullptr; double* d_pts = nullptr;
     HIPCHK(g, hipMalloc(&d_sh, std::max(1, nshapes) * sizeof(Shape)));
     HIPCHK(g, hipMalloc(&d_pts, std::max(1, npts) * 2 * sizeof(double)));
     if (nshapes) HIPCHK(g, hipMemcpyAsync(d_sh, shapes, nshapes * sizeof(Shape), hipMemcpyHostToDevice, g->stream));
     if (npts) HIPCHK(g, hipMemcpyAsync(d_pts, pts, (size_t)npts * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    tm("alloc + h2d");
     // From a handful of shapes on they are binned by tile, on the device (cg_mask_bin.hip.h): count, scan, fill.  The one
     // number the host needs in between is the length of the lists.
     static const int min_shapes = [] { const char* e = getenv("CG_MASK_BIN_MIN"); return e ? atoi(e) : 8; }();
@@ -1591,6 +1599,7 @@ int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const d
         unsigned ctr[4] = {0, 0, 0, 0};
         HIPCHK(g, hipMemcpyAsync(ctr, d_ctr, sizeof ctr, hipMemcpyDeviceToHost, g->stream));
         HIPCHK(g, hipStreamSynchronize(g->stream));
+        tm("ranges + scan");
         if (!ctr[2] && ctr[0] <= (unsigned)WIDE_CAP && ctr[1] <= (1u << 27)) {
             HIPCHK(g, hipMalloc(&d_list, std::max<size_t>(ctr[1], 1) * sizeof(int)));
             HIPCHK(g, hipMemcpyAsync(d_cur, d_off, b_cnt, hipMemcpyDeviceToDevice, g->stream));
@@ -1605,7 +1614,9 @@ int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const d
                            d_pts, buf);
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipStreamSynchronize(g->stream));
+    tm("fill + raster");
     (void)hipFree(d_sh); (void)hipFree(d_pts); if (d_bin) (void)hipFree(d_bin); if (d_list) (void)hipFree(d_list);
+    tm("free");
     return CG_OK;
 }
 
