@@ -57,13 +57,20 @@ __device__ inline bool shape_box_dev(const Shape& s, const double* __restrict__ 
 // Pass 1: the tile range of every shape; counts[tile] += 1 for the tiles of the narrow ones; the wide ones (more than
 // wide_area tiles, or no box) go to `wide` (counter[0] = how many; beyond wide_cap they are only counted).
 // counter[1] = total length of the tile lists (may exceed what fits an int: saturates at 2^31 - 1).
+// counter[3] != 0: a polygon names points outside [0, npts) (the host refuses the list).
 static __global__ __launch_bounds__(256) void k_shape_ranges(int nx, int ny, int i0g, double dx, double dy, const Shape* __restrict__ shapes, int nshapes,
                                                              const double* __restrict__ pts, int tn_i, int tn_j, unsigned wide_area, TileRange* __restrict__ rg,
-                                                             int* __restrict__ counts, int* __restrict__ wide, int wide_cap, unsigned* __restrict__ counter) {
+                                                             int* __restrict__ counts, int* __restrict__ wide, int wide_cap, unsigned* __restrict__ counter, int npts) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nshapes) return;
     double x0, x1, y0, y1;
     TileRange r{0, tn_i - 1, 0, tn_j - 1};
+    // a polygon whose points lie outside the table: reported (counter[3] = 1 + the largest such shape), never looked at
+    if (shapes[s].type == CG_SHAPE_POLYGON && (shapes[s].pt_off < 0 || shapes[s].pt_cnt < 0 || (long long)shapes[s].pt_off + shapes[s].pt_cnt > npts)) {
+        atomicMax(&counter[3], (unsigned)s + 1u);
+        rg[s] = TileRange{0, -1, 0, -1};
+        return;
+    }
     if (shape_box_dev(shapes[s], pts, x0, x1, y0, y1)) {
         if (x1 < x0 || y1 < y0) { rg[s] = TileRange{0, -1, 0, -1}; return; }
         // cell centres are (i + 0.5) * dx: one cell of slack on each side

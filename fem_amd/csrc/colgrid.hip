@@ -164,6 +164,8 @@ struct cg_grid {
     size_t seed_stride = 0, seed_off = 0; int seed_rows = 0; bool seed_lo = false, seed_hi = false;
     int* d_bbox = nullptr;
     uint32_t* d_sink = nullptr;                            // 4 MiB that nobody reads (StreamOpts::sink)
+    char* mask_tab = nullptr; size_t mask_tab_cap = 0;     // cg_mask_from_shapes: shape table, points, bins (grow-only, see cg_release_scratch)
+    int* mask_list = nullptr; size_t mask_list_cap = 0;    // ... and the per-tile shape lists
     uint8_t* cand = nullptr;                               // strip_connected: columns that still hold an unmarked node
     uint32_t* uf = nullptr; size_t uf_cap = 0;             // strip_connected: the union-find forest over the nodes (uf_cap words), kept until cg_release_scratch
     bool uf_on = false, uf_joined = false;                 // this flood runs on the forest / the forest has been joined
@@ -1427,6 +1429,8 @@ int cg_destroy(cg_grid* g) {
     if (g->d_bbox) (void)hipFree(g->d_bbox);
     if (g->cand) (void)hipFree(g->cand);
     if (g->d_sink) (void)hipFree(g->d_sink);
+    if (g->mask_tab) (void)hipFree(g->mask_tab);
+    if (g->mask_list) (void)hipFree(g->mask_list);
     if (g->uf) (void)hipFree(g->uf);
     if (g->d_ald_taps) (void)hipFree(g->d_ald_taps);
     free_alt(g, 0); free_alt(g, 1); drop_seeds(g);
@@ -1555,53 +1559,76 @@ int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const d
     NEED_H(g);
     if (!mask_id || nshapes < 0 || npts < 0 || (nshapes > 0 && !shapes) || (npts > 0 && !pts))
         return fail(g, CG_ERR_ARG, "bad shape list");
-    for (int s = 0; s < nshapes; s++)
-        if (shapes[s].type == CG_SHAPE_POLYGON && (shapes[s].pt_off < 0 || shapes[s].pt_cnt < 0 || shapes[s].pt_off + shapes[s].pt_cnt > npts))
-            return fail(g, CG_ERR_ARG, "shape %d: polygon points [%d,+%d) outside the %d given", s, shapes[s].pt_off, shapes[s].pt_cnt, npts);
+    // (a polygon must name points inside the table: checked here for the lists the one-pass rasteriser walks, by
+    // k_shape_ranges for the long ones -- a pass of the host over half a million records costs a millisecond)
+    const auto check_polygons = [&]() -> int {
+        for (int s = 0; s < nshapes; s++)
+            if (shapes[s].type == CG_SHAPE_POLYGON && (shapes[s].pt_off < 0 || shapes[s].pt_cnt < 0 || (long long)shapes[s].pt_off + shapes[s].pt_cnt > npts))
+                return fail(g, CG_ERR_ARG, "shape %d: polygon points [%d,+%d) outside the %d given", s, shapes[s].pt_off, shapes[s].pt_cnt, npts);
+        return CG_OK;
+    };
     static_assert(sizeof(Shape) == sizeof(cg_shape), "Shape mirrors cg_shape");
     static const bool tm_on = getenv("CG_MASK_TIMING") != nullptr;
     auto tm_now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tm0 = tm_now();
     auto tm = [&](const char* what) { if (!tm_on) return; (void)hipStreamSynchronize(g->stream); const double t1 = tm_now(); fprintf(stderr, "  [mask] %-18s %.3f ms\n", what, t1 - tm0); tm0 = t1; };
-    tm("check");
-    uint8_t* buf; int rc = new_mask_slot(g, &buf, mask_id); if (rc) return rc;
-    tm("raster alloc");
-    Shape* d_sh = nullptr; double* d_pts = nullptr;
-    HIPCHK(g, hipMalloc(&d_sh, std::max(1, nshapes) * sizeof(Shape)));
-    HIPCHK(g, hipMalloc(&d_pts, std::max(1, npts) * 2 * sizeof(double)));
-    if (nshapes) HIPCHK(g, hipMemcpyAsync(d_sh, shapes, nshapes * sizeof(Shape), hipMemcpyHostToDevice, g->stream));
-    if (npts) HIPCHK(g, hipMemcpyAsync(d_pts, pts, (size_t)npts * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
-    tm("alloc + h2d");
+    tm("start");
     // From a handful of shapes on they are binned by tile, on the device (cg_mask_bin.hip.h): count, scan, fill.  The one
     // number the host needs in between is the length of the lists.
     static const int min_shapes = [] { const char* e = getenv("CG_MASK_BIN_MIN"); return e ? atoi(e) : 8; }();
     const int tn_i = (g->nx + MASK_TILE - 1) / MASK_TILE, tn_j = (g->ny + MASK_TILE - 1) / MASK_TILE;
     const size_t ntiles = (size_t)tn_i * tn_j;
     constexpr int WIDE_CAP = 64;                                // more wide shapes than this: every cell would walk them all anyway
-    char* d_bin = nullptr; int* d_list = nullptr;
+    const bool bin = nshapes >= min_shapes && ntiles <= (size_t)INT32_MAX / 2;
+    if (!bin) { int rcc = check_polygons(); if (rcc) return rcc; }
+    // one piece of device memory that the handle keeps between calls: shapes | points | ranges | counts | offsets | cursors | wide | counters
+    const auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t b_sh = up16(std::max(1, nshapes) * sizeof(Shape)), b_pts = up16((size_t)std::max(1, npts) * 2 * sizeof(double));
+    const size_t b_rg = bin ? (size_t)nshapes * sizeof(TileRange) : 0, b_cnt = bin ? ntiles * sizeof(int) : 0, b_off = bin ? (ntiles + 1) * sizeof(int) : 0;
+    const size_t o_pts = b_sh, o_rg = o_pts + b_pts, o_cnt = o_rg + up16(b_rg), o_off = o_cnt + up16(b_cnt), o_cur = o_off + up16(b_off);
+    const size_t o_wide = o_cur + up16(b_cnt), o_ctr = o_wide + WIDE_CAP * sizeof(int), total_b = o_ctr + 4 * sizeof(unsigned);
+    if (g->mask_tab_cap < total_b) {
+        if (g->mask_tab) { HIPCHK(g, hipStreamSynchronize(g->stream)); (void)hipFree(g->mask_tab); g->mask_tab = nullptr; g->mask_tab_cap = 0; }
+        HIPCHK(g, hipMalloc(&g->mask_tab, total_b + total_b / 4));
+        g->mask_tab_cap = total_b + total_b / 4;
+    }
+    char* const tab = g->mask_tab;
+    Shape* d_sh = (Shape*)tab; double* d_pts = (double*)(tab + o_pts);
+    if (nshapes) HIPCHK(g, hipMemcpyAsync(d_sh, shapes, nshapes * sizeof(Shape), hipMemcpyHostToDevice, g->stream));
+    if (npts) HIPCHK(g, hipMemcpyAsync(d_pts, pts, (size_t)npts * 2 * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    tm("tables + h2d");
+    uint8_t* buf = nullptr;
+    int* d_list = nullptr;
     ProfScope ps(g, CG_K_MASK);
     bool binned = false;
-    if (nshapes >= min_shapes && ntiles <= (size_t)INT32_MAX / 2) {
-        // one allocation: ranges | counts | offsets | cursors | wide | counters
-        const size_t b_rg = (size_t)nshapes * sizeof(TileRange), b_cnt = ntiles * sizeof(int), b_off = (ntiles + 1) * sizeof(int);
-        const size_t o_cnt = (b_rg + 15) & ~(size_t)15, o_off = o_cnt + ((b_cnt + 15) & ~(size_t)15), o_cur = o_off + ((b_off + 15) & ~(size_t)15);
-        const size_t o_wide = o_cur + ((b_cnt + 15) & ~(size_t)15), o_ctr = o_wide + WIDE_CAP * sizeof(int), total_b = o_ctr + 4 * sizeof(unsigned);
-        HIPCHK(g, hipMalloc(&d_bin, total_b));
-        TileRange* d_rg = (TileRange*)d_bin; int* d_cnt = (int*)(d_bin + o_cnt); int* d_off = (int*)(d_bin + o_off); int* d_cur = (int*)(d_bin + o_cur);
-        int* d_wide = (int*)(d_bin + o_wide); unsigned* d_ctr = (unsigned*)(d_bin + o_ctr);
+    if (bin) {
+        TileRange* d_rg = (TileRange*)(tab + o_rg); int* d_cnt = (int*)(tab + o_cnt); int* d_off = (int*)(tab + o_off); int* d_cur = (int*)(tab + o_cur);
+        int* d_wide = (int*)(tab + o_wide); unsigned* d_ctr = (unsigned*)(tab + o_ctr);
         HIPCHK(g, hipMemsetAsync(d_cnt, 0, b_cnt, g->stream));
         HIPCHK(g, hipMemsetAsync(d_ctr, 0, 4 * sizeof(unsigned), g->stream));
         const unsigned wide_area = (unsigned)std::max<size_t>(64, ntiles / 64);
         hipLaunchKernelGGL(k_shape_ranges, dim3((unsigned)((nshapes + 255) / 256)), dim3(256), 0, g->stream, g->nx, g->ny, g->i0, g->dx, g->dy, d_sh, nshapes,
-                           d_pts, tn_i, tn_j, wide_area, d_rg, d_cnt, d_wide, WIDE_CAP, d_ctr);
+                           d_pts, tn_i, tn_j, wide_area, d_rg, d_cnt, d_wide, WIDE_CAP, d_ctr, npts);
         hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, g->stream, d_cnt, (int)ntiles, d_off);
         HIPCHK(g, hipGetLastError());
         unsigned ctr[4] = {0, 0, 0, 0};
         HIPCHK(g, hipMemcpyAsync(ctr, d_ctr, sizeof ctr, hipMemcpyDeviceToHost, g->stream));
         HIPCHK(g, hipStreamSynchronize(g->stream));
         tm("ranges + scan");
+        if (ctr[3]) {
+            const cg_shape& b = shapes[ctr[3] - 1];
+            return fail(g, CG_ERR_ARG, "shape %u: polygon points [%d,+%d) outside the %d given", ctr[3] - 1, b.pt_off, b.pt_cnt, npts);
+        }
+        { int rc = new_mask_slot(g, &buf, mask_id); if (rc) return rc; }
+        tm("raster alloc");
         if (!ctr[2] && ctr[0] <= (unsigned)WIDE_CAP && ctr[1] <= (1u << 27)) {
-            HIPCHK(g, hipMalloc(&d_list, std::max<size_t>(ctr[1], 1) * sizeof(int)));
+            if (g->mask_list_cap < ctr[1]) {
+                if (g->mask_list) { (void)hipFree(g->mask_list); g->mask_list = nullptr; g->mask_list_cap = 0; }      // (the stream is idle: synchronised above)
+                const size_t want = (size_t)ctr[1] + ctr[1] / 4 + 1;
+                HIPCHK(g, hipMalloc(&g->mask_list, want * sizeof(int)));
+                g->mask_list_cap = want;
+            }
+            d_list = g->mask_list;
             HIPCHK(g, hipMemcpyAsync(d_cur, d_off, b_cnt, hipMemcpyDeviceToDevice, g->stream));
             hipLaunchKernelGGL(k_shape_fill, dim3((unsigned)((nshapes + 255) / 256)), dim3(256), 0, g->stream, d_rg, nshapes, tn_j, d_cur, d_list);
             hipLaunchKernelGGL(k_mask_shapes_tiles, dim3((unsigned)ntiles), dim3(256), 0, g->stream, g->nx, g->ny, g->i0, g->dx, g->dy, d_sh, d_pts,
@@ -1609,14 +1636,15 @@ int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes, const d
             binned = true;
         }
     }
-    if (!binned)
+    if (!binned) {
+        if (!buf) { int rc = new_mask_slot(g, &buf, mask_id); if (rc) return rc; }
         hipLaunchKernelGGL(k_mask_shapes, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, g->nx, g->ny, g->i0, g->dx, g->dy, d_sh, nshapes,
                            d_pts, buf);
+    }
     HIPCHK(g, hipGetLastError());
     HIPCHK(g, hipStreamSynchronize(g->stream));
     tm("fill + raster");
-    (void)hipFree(d_sh); (void)hipFree(d_pts); if (d_bin) (void)hipFree(d_bin); if (d_list) (void)hipFree(d_list);
-    tm("free");
+    // (the host's shape table has been read and the raster is complete; the device tables stay with the handle)
     return CG_OK;
 }
 
@@ -2451,6 +2479,8 @@ int cg_release_scratch(cg_grid* g) {
     HIPCHK(g, hipStreamSynchronize(g->stream));
     free_alt(g, 0); free_alt(g, 1);
     if (g->uf) { (void)hipFree(g->uf); g->uf = nullptr; g->uf_cap = 0; g->uf_on = false; }
+    if (g->mask_tab) { (void)hipFree(g->mask_tab); g->mask_tab = nullptr; g->mask_tab_cap = 0; }
+    if (g->mask_list) { (void)hipFree(g->mask_list); g->mask_list = nullptr; g->mask_list_cap = 0; }
     return CG_OK;
 }
 

@@ -161,7 +161,10 @@ int cg_mask_from_device_raster(cg_grid* g, const void* dev_raster, size_t n, int
 /* From the shape list of a mask record: _isPointBlocked(x, y, maskData) (rt:54-71) run on
  * the device.  shapes[] are the VISIBLE objects in their original order; the walk is from
  * the last to the first and the first containing shape decides.  pts = polygon vertices
- * (x0,y0,x1,y1,...), npts = number of doubles / 2. */
+ * (x0,y0,x1,y1,...), npts = number of doubles / 2.  A polygon that names points outside
+ * [0, npts) is refused (CG_ERR_ARG).  The device copies of the shape table and the per-tile
+ * lists made from it stay with the handle for the next call (about 80 bytes per shape of the
+ * longest list so far; cg_release_scratch frees them). */
 int cg_mask_from_shapes(cg_grid* g, const cg_shape* shapes, int nshapes,
                         const double* pts, int npts, int* mask_id);
 
@@ -290,7 +293,8 @@ int cg_ald_coat_slab(cg_grid* g, int mat, double t, uint32_t hmax_q);
 int cg_ald_merge_slab(cg_grid* g, uint32_t hbase_q);
 
 /* Frees the second and third set of planes that etch_wet / deposit_ALD steps work in
- * (they are as large as the grid itself).  No counterpart in the reference. */
+ * (they are as large as the grid itself) and the tables cg_mask_from_shapes keeps.  No
+ * counterpart in the reference. */
 int cg_release_scratch(cg_grid* g);
 
 /* addLayer(i, j, matId, z0, z1) (cg1:196-211): appends one layer to column (i, j), heights

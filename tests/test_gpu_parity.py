@@ -779,6 +779,36 @@ def test_vertical_steps_inside_lateral_deposits(nx, ny, seed):
     _check_steps_inside_lateral_deposits(nx, ny, seed, 0)
 
 
+@pytest.mark.parametrize("nshapes", [5, 40])
+def test_polygon_with_points_outside_the_table_is_refused(nshapes):
+    """A polygon record that names points outside the point table is refused before anything reads them: by the host's
+    pass over a short list, by the binning kernel for a long one (from 8 shapes on).  The handle goes on working and
+    the same list with the record repaired rasterises like the oracle's."""
+    fem = _engine()
+    nx, ny = 96, 128
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    rng = _lcg(77)
+    data = _random_mask_data(rng, 2 * max(nx, ny), nshapes)
+    red, plain = fem.reduce_mask(data, packed=True), fem.reduce_mask(data)      # (the oracle's wrapper reads the list form)
+    sh = red["shapes"]
+    poly = [k for k in range(len(sh)) if sh["type"][k] == fem.colgrid.SHAPE_POLYGON]
+    assert poly, "the seeded list holds no polygon"
+    k = poly[-1]
+    good = int(sh["pt_off"][k])
+    for bad in (len(red["pts"]) // 2 - int(sh["pt_cnt"][k]) + 1, -1):
+        sh["pt_off"][k] = bad
+        with pytest.raises(fem.ColGridError) as e:
+            g.mask_from_shapes(red)
+        assert "polygon points" in str(e.value) and f"shape {k}" in str(e.value)
+    sh["pt_off"][k] = good
+    m = g.mask_from_shapes(red)
+    np.testing.assert_array_equal(m.download(), o.mask_raster(plain))
+    g.deposit_general(m, 3, 5, 0); o.deposit_general(o.mask_raster(plain), 3, 5, 0)
+    assert g.checksum() == o.checksum()
+    g.close()
+
+
 @pytest.mark.parametrize("nx,ny,seed,parts", [(512, 256, 31, 2), (768, 256, 32, 3), (640, 128, 33, 2), (600, 512, 34, 3), (520, 260, 35, 2)])
 def test_vertical_steps_inside_lateral_deposits_on_slabs(nx, ny, seed, parts):
     """The same on a grid cut into slabs (cg_group_*): a slab's deposit waits as well, the steps behind it go out inside
