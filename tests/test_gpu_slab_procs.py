@@ -59,7 +59,11 @@ def test_bench_weak_scaling_rehearsal():
     b = json.loads([l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert b["scaling"] == "weak" and b["n_gpus"] == 2 and b["config"]["world"] == 2
     assert b["config"]["grid"] == [512, 256] and b["config"]["rows_per_gpu"] == 256
-    assert b["halo"]["bytes_sent_per_rank"] > 0 and b["fusion"]["fused_launches"] == 3
+    assert b["halo"]["bytes_sent_per_rank"] > 0
+    # a slab's lateral deposits take the vertical steps behind them along (three of them in a pass of C4), the run on the
+    # reset grid goes out on its own; and the library's launch counters agree with the bench's rule for every kernel group
+    assert b["fusion"]["fused_launches"] == 1 and b["fusion"]["lateral_deposits_with_steps_inside"] == 3
+    assert b["schedule"] == "fold" and not [k for k, v in b["kernels"].items() if "launches_by_bench_rule" in v]
 
 
 @pytest.mark.gpu
