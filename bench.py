@@ -303,6 +303,12 @@ def main():
         folding = fusing and not os.environ.get("CG_NO_FOLD") and not slice_idx
         FOLDED = "k_stencil<deposit+vertical>"
         launches, cur = [], None              # (kernel group, [step indices]); cur = a launch that may still take steps: [kind, steps, room]
+        # On a slab the run on the reset grid goes along with the deposit behind it when the transfers are ordered by streams
+        # (RCCL); when they are staged through the host the synchronisation in front of them launches the run on its own.
+        # Either way the rows that the slab's edge launches read get the run when the step is opened: one more fused launch
+        # per edge band (rank 0 has one band).
+        front_ok = folding and (world == 1 or slab.device_side_comm())
+        front_of, edge_runs = {}, 0           # launch index -> steps of the run in front of its deposit
 
         def close():
             nonlocal cur
@@ -332,7 +338,11 @@ def main():
             else:
                 s_ = flow[idx]
                 small = math.ceil(max(0.0, s_["t"]) * max(0.0, min(1.0, s_["S"])) / 2.0) <= 4
-                if folding and world == 1 and kd == "k_stencil<deposit>" and cur and cur[0] == "run" and cur[1][0] == 0 and s_["mask"] is None:
+                after_run = kd == "k_stencil<deposit>" and cur and cur[0] == "run" and cur[1][0] == 0 and s_["mask"] is None
+                if folding and world > 1 and after_run:
+                    edge_runs += 1
+                if front_ok and after_run:
+                    front_of[len(launches)] = len(cur[1])
                     cur = ["lat", cur[1] + [idx], FUSE_MAX - 1 if small else 0]
                     if cur[2] == 0:
                         close()
@@ -358,12 +368,13 @@ def main():
         # timed scopes the library opens per launch of the list above: one on an undivided grid; on a slab a lateral
         # step has two (the rows that read no message, the rows that do) and a deposit with steps inside has its own, a
         # plain deposit scope for the edge rows and a fused launch per edge band for the steps there (rank 0: one band)
-        expected = {}
-        for grp, _ in launches:
+        expected = {"k_vertical_fused": edge_runs} if edge_runs else {}
+        for li, (grp, steps) in enumerate(launches):
             if world > 1 and grp in ("k_stencil<etch>", "k_stencil<deposit>"):
                 expected[grp] = expected.get(grp, 0) + 2
             elif world > 1 and grp == FOLDED:
-                for nm in (FOLDED, "k_stencil<deposit>", "k_vertical_fused"):
+                behind = len(steps) - 1 - front_of.get(li, 0)
+                for nm in (FOLDED, "k_stencil<deposit>") + (("k_vertical_fused",) if behind > 0 else ()):
                     expected[nm] = expected.get(nm, 0) + 1
             else:
                 expected[grp] = expected.get(grp, 0) + 1

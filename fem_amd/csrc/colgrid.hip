@@ -1172,18 +1172,28 @@ bool fresh_table(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, FreshTab& T)
     return true;
 }
 
-bool fresh_run(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, int* rc) {
+// off / count: the columns [off, off + count) only (count a multiple of the 4096 columns a workgroup takes; the kernel then
+// sees a grid that begins at `off`, its plane stride stays N).  What the kernel stores depends on the masks alone, so a
+// column may be written by several such launches, or by one of them and by a lateral launch of the FRESH form.
+bool fresh_run(cg_grid* g, const std::vector<cg_grid::VQOp>& ops, int* rc, size_t off = 0, size_t count = 0) {
     *rc = CG_OK;
     FreshTab T;
     if (!fresh_table(g, ops, T)) return false;
-    const size_t nb = (g->N / 4 + (size_t)256 * FRESH_U - 1) / ((size_t)256 * FRESH_U);
+    GridView gv = view(g);
+    if (count) {
+        if (count % (1024 * FRESH_U) != 0 || off % 4 != 0 || off + count > g->N) { *rc = fail(g, CG_ERR_STATE, "a run on the reset grid over columns %zu + %zu", off, count); return true; }
+        gv.top += off; gv.top_w += off; gv.rec += off;
+        for (int q = 0; q < T.nmask; q++) T.mask[q] += off;
+    }
+    const size_t ncol = count ? count : g->N;
+    const size_t nb = (ncol / 4 + (size_t)256 * FRESH_U - 1) / ((size_t)256 * FRESH_U);
     ProfScope ps(g, CG_K_VERTICAL_FUSED);
     const dim3 grid((unsigned)std::max<size_t>(1, nb));
     switch (T.nmask) {
-    case 0: hipLaunchKernelGGL(k_vertical_fresh<0>, grid, dim3(256), 0, g->stream, view(g), T); break;
-    case 1: hipLaunchKernelGGL(k_vertical_fresh<1>, grid, dim3(256), 0, g->stream, view(g), T); break;
-    case 2: hipLaunchKernelGGL(k_vertical_fresh<2>, grid, dim3(256), 0, g->stream, view(g), T); break;
-    default: hipLaunchKernelGGL(k_vertical_fresh<3>, grid, dim3(256), 0, g->stream, view(g), T); break;
+    case 0: hipLaunchKernelGGL(k_vertical_fresh<0>, grid, dim3(256), 0, g->stream, gv, T); break;
+    case 1: hipLaunchKernelGGL(k_vertical_fresh<1>, grid, dim3(256), 0, g->stream, gv, T); break;
+    case 2: hipLaunchKernelGGL(k_vertical_fresh<2>, grid, dim3(256), 0, g->stream, gv, T); break;
+    default: hipLaunchKernelGGL(k_vertical_fresh<3>, grid, dim3(256), 0, g->stream, gv, T); break;
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) *rc = fail(g, CG_ERR_HIP, "k_vertical_fresh: %s", hipGetErrorString(e));
@@ -1253,6 +1263,29 @@ int boundary_column_ranges(const cg_grid* g, const ConfKernel* K, int R, bool lo
     return n;
 }
 
+// The columns a slab's edge launches READ: the rows of the edge bands and R rows beyond them, as ranges of whole
+// workgroups of k_vertical_fresh (4096 columns), the upper one ending with the slab.  False: the slab is too thin for that
+// to leave anything out.
+bool edge_read_ranges(const cg_grid* g, const ConfKernel* K, int R, bool lower, bool upper, size_t off[2], size_t count[2], int* n) {
+    Band bb[2];
+    const int ti = stream_tile_rows(K->Re);
+    const int nb = stencil_bands(g->nx, ti, R, lower, upper, 2 /* PART_BOUNDARY */, bb);
+    const size_t unit = (size_t)1024 * FRESH_U;
+    size_t covered = 0;
+    *n = 0;
+    for (int b = 0; b < nb; b++) {
+        const int r0 = std::max(0, bb[b].t0 * ti - R), r1 = std::min(g->nx, (bb[b].t0 + bb[b].n) * ti + R);
+        const size_t a = (size_t)r0 * g->ny, e = (size_t)r1 * g->ny;
+        size_t o, c;
+        if (bb[b].t0 == 0) { o = 0; c = (e + unit - 1) / unit * unit; }
+        else { c = (g->N - a + unit - 1) / unit * unit; if (c > g->N) return false; o = g->N - c; }
+        if (o + c > g->N || o % 4 != 0) return false;
+        off[*n] = o; count[*n] = c; (*n)++;
+        covered += c;
+    }
+    return covered < g->N;
+}
+
 int flush_vertical(cg_grid* g) {
     if (g->lat.active) {
         // the waiting lateral deposit, with the vertical steps queued behind it inside its launch when there are any
@@ -1277,8 +1310,10 @@ int flush_vertical(cg_grid* g) {
         if (pre && !fresh_table(g, L.pre, T)) return fail(g, CG_ERR_STATE, "the waiting run of vertical steps no longer fits the table form");
         if (L.halo_lo || L.halo_up) {
             // a slab: the steps behind go out inside the launch over the rows that read no message; the other rows get
-            // the deposit from the kernel that reads the messages and then the steps in a pass of their own
-            int rc = launch_stencil(g, false, L.mask, L.mat, L.t_eff, L.R, L.K, -1, L.halo_lo, L.halo_up, L.P, 1 /* PART_INTERIOR */, false, fold ? &F : nullptr, nullptr);
+            // the deposit from the kernel that reads the messages and then the steps in a pass of their own.  A run on the
+            // reset grid in front of the deposit is put together from its masks by the first launch; the rows the second
+            // one reads got it when the step was opened (cg_stencil_begin).
+            int rc = launch_stencil(g, false, L.mask, L.mat, L.t_eff, L.R, L.K, -1, L.halo_lo, L.halo_up, L.P, 1 /* PART_INTERIOR */, false, fold ? &F : nullptr, pre ? &T : nullptr);
             if (rc) return rc;
             rc = launch_stencil(g, false, L.mask, L.mat, L.t_eff, L.R, L.K, -1, L.halo_lo, L.halo_up, L.P, 2 /* PART_BOUNDARY */, false, nullptr, nullptr);
             if (rc) return rc;
@@ -1693,10 +1728,12 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     // A lateral deposit without a mask that finds a run of vertical steps waiting on the reset grid leaves it waiting:
     // when the deposit takes the lean kernel (known further down) the run goes out inside that launch.
     static const bool no_fold = getenv("CG_NO_FOLD") != nullptr;
-    bool prefold = !no_fold && !can_fuse && kind == CG_STENCIL_DEPOSIT && !mask && !has_lower && !has_upper && g->nx == g->nx_global && g->fuse &&
+    const bool slab = has_lower || has_upper;
+    bool prefold = !no_fold && !can_fuse && kind == CG_STENCIL_DEPOSIT && !mask && (slab || g->nx == g->nx_global) && g->fuse &&
                    !g->stats_on && !g->lat.active && !g->vq.empty() && g->vq[0].fresh && g->split && !g->has_gaps && !g->has_cavity &&
                    g->len_bound + 1 <= g->lmax_vis && g->len_bound < g->lmax && g->nextp < std::min(g->lmax, SPLIT_PLANES);
     if (prefold) { FreshTab probe; prefold = fresh_table(g, g->vq, probe); }
+    if (prefold && slab && g->N % ((size_t)1024 * FRESH_U) != 0) prefold = false;
     if (!can_fuse && !prefold) { int rcf = flush_vertical(g); if (rcf) return rcf; }
     // a reset grid whose first step is a deposit everywhere needs no clearing pass: the kernel writes
     // top of every column itself
@@ -1725,9 +1762,15 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
     }
     ConfKernel* K = get_kernel(g, t, S);
     const int R = K->Rx;
+    size_t pre_off[2] = {0, 0}, pre_count[2] = {0, 0}; int pre_n = 0;
     if (prefold) {
+        // (the form is known once the kernel's device tables exist: a kernel seen for the first time gets them here)
+        if (K->Ry <= K->Rx) { int rcu = upload_taps(g, K, R); if (rcu) return rcu; }
         const StencilForm form = stencil_form(g, K, false, mat, -1, false);
-        if (!(form.streams && form.lean)) { prefold = false; int rcf = flush_vertical(g); if (rcf) return rcf; }
+        bool ok_pre = form.streams && form.lean;
+        // on a slab the rows that the edge launches read get the run right away (the rows to send are packed from them)
+        if (ok_pre && slab) ok_pre = edge_read_ranges(g, K, R, has_lower != 0, has_upper != 0, pre_off, pre_count, &pre_n);
+        if (!ok_pre) { prefold = false; int rcf = flush_vertical(g); if (rcf) return rcf; }
     }
     // The reference pads its height map by Rx cells in BOTH directions (script_columngrid.js:471, 666) while the taps reach
     // Ry = ceil(t/dy) cells along j.  With Ry <= Rx (any dy >= dx) every tap stays inside the pad and the step is well
@@ -1756,6 +1799,13 @@ int cg_stencil_begin(cg_grid* g, int kind, int mask_id, int mat, double thicknes
         hipLaunchKernelGGL(k_snapshot_tops, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g));
         HIPCHK(g, hipGetLastError());
     }
+    if (prefold && slab) {
+        for (int b = 0; b < pre_n; b++) {
+            int rcr = 0;
+            if (!fresh_run(g, g->vq, &rcr, pre_off[b], pre_count[b])) return fail(g, CG_ERR_STATE, "the waiting run of vertical steps no longer fits the table form");
+            if (rcr) return rcr;
+        }
+    }
     if (has_lower || has_upper) {
         ProfScope ps(g, CG_K_HALO);
         hipLaunchKernelGGL(k_halo_pack, dim3(blocks_for((size_t)R * g->ny)), dim3(256), 0, g->stream, view(g), mask, mat,
@@ -1781,8 +1831,8 @@ int cg_kernel_cache_touch(cg_grid* g, double thickness, double conformality) {
 }
 
 int cg_halo_buffers(cg_grid* g, void** send_lower, void** send_upper, void** recv_lower, void** recv_upper, size_t* bytes_each) {
-    NEED_H(g);
-    if (!g->pend.active) return fail(g, CG_ERR_STATE, "no stencil step is open");
+    NEED_H0(g);
+    if (!g->pend.active) { NEED_H(g); return fail(g, CG_ERR_STATE, "no stencil step is open"); }      // (an open step may have left a run of vertical steps waiting for it)
     if (send_lower) *send_lower = g->halo[0];
     if (send_upper) *send_upper = g->halo[1];
     if (recv_lower) *recv_lower = g->halo[2];
@@ -1839,7 +1889,7 @@ static bool deposit_can_wait(cg_grid* g, const Pending& p, bool slab) {
     if (!slab) {
         if (g->nx != g->nx_global || !(p.K->Re <= LEAN_FOLD_MAX_R || (p.prefold && !g->vq.empty()))) return false;
     } else {
-        if (p.K->Re > LEAN_FOLD_MAX_R || p.prefold) return false;
+        if (!(p.K->Re <= LEAN_FOLD_MAX_R || (p.prefold && !g->vq.empty()))) return false;
         // the rows that read a message take the steps in launches of whole workgroups; the others must exist
         size_t off[2], count[2];
         const int nr = boundary_column_ranges(g, p.K, p.R, p.has_lower, p.has_upper, off, count);
@@ -1852,8 +1902,10 @@ static bool deposit_can_wait(cg_grid* g, const Pending& p, bool slab) {
 }
 
 int cg_stencil_interior(cg_grid* g) {
-    NEED(g);
-    if (!g->pend.active) return fail(g, CG_ERR_STATE, "no stencil step is open");
+    NEED_H0(g);
+    if (!g->pend.active) { NEED(g); return fail(g, CG_ERR_STATE, "no stencil step is open"); }
+    // (a run of vertical steps left waiting for this deposit stays in its queue for now)
+    if (!(g->pend.prefold && !g->lat.active && !g->vq.empty() && g->vq[0].fresh)) { g->pend.prefold = false; NEED(g); }
     if (g->pend.interior_done) return fail(g, CG_ERR_STATE, "the interior of this step has been launched already");
     if (!g->pend.has_lower && !g->pend.has_upper) return CG_OK;            // nothing is in flight: finish does it all
     bool ok; const uint8_t* mask = mask_ptr(g, g->pend.mask_id, &ok);
@@ -1865,6 +1917,11 @@ int cg_stencil_interior(cg_grid* g) {
         // the deposit will wait for the vertical steps behind it (cg_stencil_finish): nothing goes out yet
         g->pend.interior_done = true; g->pend.held = true;
         return CG_OK;
+    }
+    if (g->pend.prefold) {                                 // not this time: the run that was left waiting goes out first
+        g->pend.prefold = false;
+        int rcf = flush_vertical(g); if (rcf) return rcf;
+        rcf = materialize(g); if (rcf) return rcf;
     }
     const uint8_t* halo_lo = p.has_lower ? g->halo[2] : nullptr;           // not read by interior tiles; they tell the bands
     const uint8_t* halo_up = p.has_upper ? g->halo[3] : nullptr;

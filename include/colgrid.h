@@ -326,6 +326,10 @@ int cg_max_height(cg_grid* g, double* z_nm, uint32_t* top_q);
  *                        halo message, so the exchange overlaps with them;
  *   cg_stencil_finish -> dilation / erosion and the per-column update (of the rows
  *                        cg_stencil_interior has not done).
+ * A deposit without a mask that finds a run of vertical steps waiting on a grid that has just been reset
+ * takes that run along as well: cg_stencil_begin then applies the run to the rows near the slab's edges
+ * only (the rows to send are packed from them) and the run stays queued while the step is open --
+ * cg_halo_buffers, cg_stencil_interior and cg_stencil_finish do not launch it, any other call does.
  * A deposit that waits for the vertical steps behind it (see the top of this file) launches nothing
  * in cg_stencil_interior nor in cg_stencil_finish: both parts go out with the queued steps, and the
  * received halo rows are read then -- they must stay untouched until the handle's next call that is

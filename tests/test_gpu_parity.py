@@ -840,6 +840,20 @@ def test_a_slabs_deposit_takes_the_steps_behind_it():
     assert prof.get("k_stencil<deposit+vertical>", (0, 0))[1] == 1, prof
     assert prof.get("k_stencil<deposit>", (0, 0))[1] == 1, prof             # (one timed scope around the two bands' launches)
     assert prof.get("k_vertical_fused", (0, 0))[1] == 2, prof
+    # the run on a reset grid in front of a deposit without a mask: the rows the edge launches read get it when the step is
+    # opened (one table launch per band), the inner rows inside the deposit's launch; no launch of the run on its own
+    g.createNewGrid()
+    g.sync()
+    g.profile(True)
+    step(0, 3, 30, 0)
+    step(0, 4, 2.0, 0)
+    step(0, 5, 9.5, 1.0)            # radius 5: takes the run in front along, nothing behind
+    g.sync()
+    prof = g.profile(False)
+    assert prof.get("k_stencil<deposit+vertical>", (0, 0))[1] == 1, prof
+    assert prof.get("k_stencil<deposit>", (0, 0))[1] == 1, prof
+    assert prof.get("k_vertical_fused", (0, 0))[1] == 2, prof               # (the two table launches over the edge rows)
+    assert "k_vertical_g4<deposit>" not in prof, prof
     g.close()
 
 
