@@ -29,4 +29,11 @@ for seed in range(70, 110):
     nx, ny = 32 + 4 * ((seed * 29) % 40), 36 + 4 * ((seed * 41) % 60)
     t._check_runs_of_vertical_steps(nx, ny, seed, [0.1, 0.05, 0.2, 0.1][seed % 4])
     print("fused runs seed", seed, nx, ny, "ok", flush=True)
+for seed in range(120, 136):
+    # lateral deposits that wait for the steps behind them (and take the run on a reset grid along): undivided grids and
+    # groups of 2..4 slabs whose slabs have inner rows (tiles are 64 rows) and whole workgroups of columns per edge band
+    parts = seed % 4 + 1
+    nx, ny = parts * (192 + 64 * (seed % 3)), [128, 256, 512, 1024][(seed // 4) % 4]
+    t._check_steps_inside_lateral_deposits(nx, ny, seed, 0 if parts == 1 else parts)
+    print("steps inside lateral deposits seed", seed, nx, ny, parts, "ok", flush=True)
 print("stress ok")
