@@ -26,8 +26,9 @@
  * Consequences for a caller that brings its own stream (cg_set_stream): when such a call returns,
  * nothing of it may be on the stream yet -- an event recorded, or dependent work enqueued, right
  * after it does not wait for the step.  cg_sync, cg_get_stream or any entry point other than a
- * vertical step puts the queued steps on the stream first; a launch error of a queued step is
- * reported by that later call.  cg_reset, cg_clear, cg_upload and cg_snapshot_load replace every
+ * vertical step puts the queued steps on the stream first (the calls that complete an open lateral
+ * step -- cg_halo_buffers, cg_stencil_interior, cg_stencil_finish -- may leave them waiting); a
+ * launch error of a queued step is reported by that later call.  cg_reset, cg_clear, cg_upload and cg_snapshot_load replace every
  * column; steps still queued are launched first all the same.
  *
  * The comment above each declaration names the reference interface it stands in for.
