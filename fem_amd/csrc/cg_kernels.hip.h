@@ -2113,6 +2113,88 @@ static __global__ __launch_bounds__(256) void k_strip_seed(GridView g, Ghost gh,
     }
 }
 
+// identify_cavity (cg2:9-83) without the pass that lays a cavity layer on top of every column: k_cavity_fill followed by
+// k_strip_seed(matId = 2) writes such a layer into nearly every column, marks it (the top of a column is exposed,
+// cg1:889), and k_strip_compact takes it out again.  All that those layers do in between is to stand next to the real
+// nodes -- the gaps and cavity layers inside the columns -- as marked neighbours; k_strip_union's air_above knows them
+// without their being there.  This kernel is the two passes for the real nodes alone: every gap becomes a cavity layer
+// (cg2:23-40), and every cavity layer is a node, marked when exposed.  With every column that is not empty reaching
+// hmax_q after the filling pass, isExposed (cg1:882-905) comes down to: resting on the floor -- no; ending at hmax_q --
+// yes; then the four neighbours in the reference's order: beyond the domain -- no, an empty column -- yes, anything else
+// reaches hmax_q and decides nothing.  The layer the filling pass would lay on a column whose top is at height 0 rests
+// on the floor and is NOT exposed: flags[0] reports such a column and the host takes the passes as they are written.
+// cand / parent / list / counts as in k_strip_seed.
+// A thread takes four neighbouring columns (N a multiple of 4): their lengths as one word, their intervals plane by plane
+// as one 16-byte load; a block visits runs of 1024 columns, dealt as k_strip_seed deals its runs of 256.
+static __global__ __launch_bounds__(256) void k_cavity_scan(GridView g, unsigned hmax_q, uint8_t* __restrict__ cand, uint32_t* __restrict__ parent,
+                                                     uint32_t* __restrict__ list, uint32_t* __restrict__ counts, size_t segcap, int* __restrict__ flags) {
+    __shared__ unsigned s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    int floor_top = 0;
+    const size_t ngroups = g.N >> 2;
+    const size_t chunks = (ngroups + 255) / 256, rounds = (chunks + gridDim.x - 1) / gridDim.x;
+    for (size_t k = 0; k < rounds; k++) {
+        const size_t q = k * gridDim.x + (blockIdx.x + 5 * k) % gridDim.x;
+        const size_t gi = q * 256 + threadIdx.x;
+        if (gi >= ngroups) continue;
+        const size_t c0 = gi << 2;
+        const unsigned lw = *(const unsigned*)(g.len + c0);
+        if (lw == 0) { *(unsigned*)(cand + c0) = 0u; continue; }
+        int l[4]; int lmx = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { l[j] = (int)((lw >> (8 * j)) & 0xffu); lmx = max(lmx, l[j]); }
+        unsigned prev[4] = {0, 0, 0, 0}, z1[4] = {0, 0, 0, 0}, cw = 0;
+        int by_nb[4] = {-1, -1, -1, -1};                       // exposed through a neighbour: not looked at yet
+        for (int kk = 0; kk < lmx; kk++) {
+            const u32x4 v = ld_rec4(g.rec + (size_t)kk * g.N + c0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (kk >= l[j]) continue;
+                uint32_t r = v[j];
+                z1[j] = rec_z1(r);
+                const bool hole = rec_hole(r);
+                if (hole || rec_mat(r) == 2) {
+                    const size_t c = c0 + j;
+                    cw |= 2u << (8 * j);
+                    if (hole) r = rec_make(z1[j], 2);          // cg2:23-40
+                    bool ex = false;
+                    if (prev[j] != 0) {
+                        if (z1[j] == hmax_q) ex = true;
+                        else {
+                            if (by_nb[j] < 0) {
+                                const int i = (int)(c / g.ny), jj = (int)(c - (size_t)i * g.ny);
+                                const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
+                                by_nb[j] = 0;
+#pragma unroll
+                                for (int d = 0; d < 4; d++) {
+                                    const int ni = i + di[d], nj = jj + dj[d];
+                                    if (ni < 0 || ni >= g.nx || nj < 0 || nj >= g.ny) break;                     // the domain edge ends the scan (cg1:896)
+                                    if (g.len[(size_t)ni * g.ny + nj] == 0) { by_nb[j] = 1; break; }
+                                }
+                            }
+                            ex = by_nb[j] != 0;
+                        }
+                    }
+                    if (ex) { r |= REC_MARK; cw |= 4u << (8 * j); }
+                    else { cw |= 1u << (8 * j); parent[(size_t)kk * g.N + c] = (uint32_t)((size_t)kk * g.N + c); }
+                    if (hole || ex) g.rec[(size_t)kk * g.N + c] = r;
+                }
+                prev[j] = z1[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (l[j] > 0 && z1[j] == 0) floor_top = 1;         // (z1: the column's top by now)
+            if (cw & (1u << (8 * j))) list[(size_t)blockIdx.x * segcap + atomicAdd(&s_n, 1u)] = (uint32_t)(c0 + j);
+        }
+        *(unsigned*)(cand + c0) = cw;
+    }
+    if (floor_top) flags[0] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_n;
+}
+
 // One relaxation sweep: an unmarked node next to an overlapping marked node becomes marked, seeing whatever marks of
 // this same sweep have already become visible.  Marks only ever get added and the closure is unique, so the order in
 // which they spread does not matter; blocks start roughly in index order, so a sweep carries marks a long way in the
@@ -2197,8 +2279,12 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
 // column with an unmarked node to look at (such columns are few, and a pass over all columns would spend its time on
 // waves with two or three busy lanes).  A pair of unmarked nodes is met from both sides; the second meeting finds them
 // joined.  A marked node needs no visit of its own: the unmarked nodes around it come to it.
+// air_above: identify_cavity without its filling pass (k_cavity_scan): every column that is not empty counts as carrying
+// a marked node of matId from its top up to the highest column of the domain, as k_cavity_fill + k_strip_seed would have
+// left it there.  An unmarked node (a0, a1] overlaps that piece of a neighbour exactly when the neighbour's top lies
+// below a1 (a1 never exceeds the highest column).
 static __global__ __launch_bounds__(256) void k_strip_union(GridView g, int matId, const uint32_t* __restrict__ list, const uint32_t* __restrict__ counts, size_t segcap,
-                                                     uint32_t* __restrict__ parent) {
+                                                     uint32_t* __restrict__ parent, int air_above) {
     const unsigned n = counts[blockIdx.x];
     const uint32_t* mine = list + (size_t)blockIdx.x * segcap;
     for (unsigned idx = threadIdx.x; idx < n; idx += blockDim.x) {
@@ -2230,6 +2316,7 @@ static __global__ __launch_bounds__(256) void k_strip_union(GridView g, int matI
                     b0 = b1;
                     if (b0 >= a1) break;
                 }
+                if (air_above && !done && ln > 0 && rec_z1(g.rec[(size_t)(ln - 1) * g.N + nn]) < a1) { uf_union(parent, ida, UF_MARKED); done = true; }
             }
         }
     }
@@ -2266,26 +2353,31 @@ static __global__ __launch_bounds__(256) void k_strip_ghost(GridView g, Ghost gh
 }
 
 // (the grid of k_strip_seed again)
+// cand bit 2 (k_cavity_scan's floods): the column holds a marked node; left (may be null): set when a node stays unmarked.
 static __global__ __launch_bounds__(256) void k_strip_spread(GridView g, int matId, uint8_t* __restrict__ cand, const uint32_t* __restrict__ list,
-                                                      const uint32_t* __restrict__ counts, size_t segcap, uint32_t* __restrict__ parent, int* __restrict__ changed) {
+                                                      const uint32_t* __restrict__ counts, size_t segcap, uint32_t* __restrict__ parent, int* __restrict__ changed,
+                                                      int* __restrict__ left) {
     const unsigned n = counts[blockIdx.x];
     const uint32_t* mine = list + (size_t)blockIdx.x * segcap;
-    int any = 0;
+    int any = 0, stays = 0;
     for (unsigned idx = threadIdx.x; idx < n; idx += blockDim.x) {
         const size_t c = mine[idx];
-        if (!(cand[c] & 1)) continue;
+        const unsigned cb = cand[c];
+        if (!(cb & 1)) continue;
         const int l = g.len[c];
-        bool open_node = false;
+        bool open_node = false, marked = false;
         for (int k = 0; k < l; k++) {
             const size_t id = (size_t)k * g.N + c;
             const uint32_t r = g.rec[id];
             if (rec_hole(r) || (r & REC_MARK) || rec_mat(r) != matId) continue;
-            if (uf_find(parent, (uint32_t)id) == UF_MARKED) { g.rec[id] = r | REC_MARK; any = 1; }
+            if (uf_find(parent, (uint32_t)id) == UF_MARKED) { g.rec[id] = r | REC_MARK; any = 1; marked = true; }
             else open_node = true;
         }
-        if (!open_node) cand[c] = 2;
+        if (!open_node || marked) cand[c] = (uint8_t)((open_node ? 1u : 0u) | 2u | (cb & 4u) | (marked ? 4u : 0u));
+        if (open_node) stays = 1;
     }
     if (any) *changed = 1;
+    if (stays && left) *left = 1;
 }
 
 // Boundary rows of a slab as ghost messages: len[ny] (padded to a multiple of 4 bytes), then
@@ -2308,10 +2400,33 @@ static __global__ __launch_bounds__(256) void k_ghost_pack(GridView g, int plane
 // removal + compaction (cg1:970-999): marked layers go; one in the middle of a column leaves a
 // gap interval (adjacent gaps merge, a gap on top goes too).  flags[2] = a gap remains somewhere,
 // flags[1] = a cavity layer (material 2) remains somewhere.
-static __global__ __launch_bounds__(256) void k_strip_compact(GridView g, int* __restrict__ flags) {
+// nodes (may be null): cand[] of a flood whose nodes were ALL the gaps and cavity layers of the grid (k_cavity_scan): a
+// column without bit 2 holds neither a mark nor a gap, and is passed over after that one byte (flags[1] then only
+// speaks for the columns looked at: the caller knows from k_strip_spread whether a cavity layer stays elsewhere).
+__device__ __forceinline__ void strip_compact_column(const GridView& g, const size_t c, int& gap, int& cav);
+static __global__ __launch_bounds__(256) void k_strip_compact(GridView g, int* __restrict__ flags, const uint8_t* __restrict__ nodes) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     int gap = 0, cav = 0;
-    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+    if (nodes && (g.N & 3) == 0) {
+        // four columns' bytes at a time (the host sizes the grid for N / 4 threads); only a column with a marked node
+        // changes (bit 2), and the gaps of the others were all turned into cavity layers by the scan
+        for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < (g.N >> 2); q += stride) {
+            const unsigned w = *(const unsigned*)(nodes + 4 * q) & 0x04040404u;
+            if (!w) continue;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (w & (4u << (8 * j))) strip_compact_column(g, 4 * q + j, gap, cav);
+        }
+    } else {
+        for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < g.N; c += stride) {
+            if (nodes && !(nodes[c] & 4)) continue;
+            strip_compact_column(g, c, gap, cav);
+        }
+    }
+    if (gap) flags[2] = 1;
+    if (cav) flags[1] = 1;
+}
+__device__ __forceinline__ void strip_compact_column(const GridView& g, const size_t c, int& gap, int& cav) {
+    {
         const int l = g.len[c];
         int w = 0, nh = 0, nc = 0;                 // intervals kept, gaps and cavity layers among them
         bool dirty = false, below_hole = false;    // below_hole: the interval at w - 1 is a gap
@@ -2333,8 +2448,6 @@ static __global__ __launch_bounds__(256) void k_strip_compact(GridView g, int* _
         if (nh > 0) gap = 1;
         if (nc > 0) cav = 1;
     }
-    if (gap) flags[2] = 1;
-    if (cav) flags[1] = 1;
 }
 
 // identify_cavity step 1 (cg2:23-71): every gap becomes a cavity layer (material 2) and every

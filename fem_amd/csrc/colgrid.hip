@@ -169,6 +169,7 @@ struct cg_grid {
     uint8_t* cand = nullptr;                               // strip_connected: columns that still hold an unmarked node
     uint32_t* uf = nullptr; size_t uf_cap = 0;             // strip_connected: the union-find forest over the nodes (uf_cap words), kept until cg_release_scratch
     bool uf_on = false, uf_joined = false;                 // this flood runs on the forest / the forest has been joined
+    unsigned uf_nblk = 0;                                  // blocks of the launch that fills the lists (the launches that read them take the same grid)
     uint32_t* uf_list = nullptr; uint32_t* uf_counts = nullptr; size_t uf_segcap = 0;    // (inside uf) columns with an unmarked node, listed per seed block
     // vertical steps queued for one fused launch (see k_vertical_fused): nothing has looked at the grid since the first
     struct VQOp { const uint8_t* mask; bool etch; int mat; double t; int P; bool fresh; };
@@ -2073,19 +2074,19 @@ int cg_ghost_pack(cg_grid* g, int planes, void* send_lower, void* send_upper) {
     return CG_OK;
 }
 
-int cg_strip_seed(cg_grid* g, int mat, int planes, const void* ghost_lower, const void* ghost_upper) {
-    NEED(g);
-    if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
-    g->pend.active = false;
-    int rc = ensure_whole(g); if (rc) return rc;
+// What a flood needs: cand[], and -- when node numbers fit 32 bits and the memory is there -- the union-find forest over
+// the nodes (interval k of column c = number k*N + c) with, behind it, the seed blocks' lists of columns that hold an
+// unmarked node and the lengths of those lists.  Without the forest the flood sweeps to its fixpoint (CG_STRIP_SWEEPS=1
+// asks for that).
+static int strip_prepare(cg_grid* g, int cols_per_thread = 1) {
     if (!g->cand) HIPCHK(g, hipMalloc(&g->cand, std::max<size_t>(g->N, 16)));
-    // The flood runs on a union-find forest over the nodes (interval k of column c = number k*N + c) when those numbers
-    // fit 32 bits and the forest fits the memory; sweeps to the fixpoint otherwise (CG_STRIP_SWEEPS=1 asks for them).
-    // Behind the forest: the seed blocks' lists of columns with an unmarked node, and the lengths of those lists.
     g->uf_on = false; g->uf_joined = false;
-    const unsigned nblk = blocks_for(g->N);
+    // (the kernel that fills the lists visits runs of 256 x cols_per_thread columns per block)
+    const size_t per = (size_t)256 * cols_per_thread;
+    const unsigned nblk = blocks_for((g->N + cols_per_thread - 1) / cols_per_thread);
+    g->uf_nblk = nblk;
     const size_t nodes = (size_t)std::max(1, std::min(g->len_bound, g->lmax)) * g->N;
-    const size_t segcap = ((g->N + (size_t)nblk * 256 - 1) / ((size_t)nblk * 256)) * 256;
+    const size_t segcap = ((g->N + (size_t)nblk * per - 1) / ((size_t)nblk * per)) * per;
     const size_t words = nodes + (size_t)nblk * segcap + nblk;
     const char* sw = getenv("CG_STRIP_SWEEPS");
     if (!(sw && sw[0] == '1') && nodes < 0xffffffffull) {          // (the highest 32-bit number stands for "marked")
@@ -2099,6 +2100,17 @@ int cg_strip_seed(cg_grid* g, int mat, int planes, const void* ghost_lower, cons
     g->uf_list = g->uf_on ? g->uf + nodes : nullptr;
     g->uf_counts = g->uf_on ? g->uf_list + (size_t)nblk * segcap : nullptr;
     g->uf_segcap = segcap;
+    return CG_OK;
+}
+
+int cg_strip_seed(cg_grid* g, int mat, int planes, const void* ghost_lower, const void* ghost_upper) {
+    NEED(g);
+    if (mat < 0 || mat > 255) return fail(g, CG_ERR_ARG, "material id %d outside 0..255", mat);
+    g->pend.active = false;
+    int rc = ensure_whole(g); if (rc) return rc;
+    { int rcp = strip_prepare(g); if (rcp) return rcp; }
+    const unsigned nblk = g->uf_nblk;
+    const size_t segcap = g->uf_segcap;
     ProfScope ps(g, CG_K_OTHER);
     hipLaunchKernelGGL(k_strip_seed, dim3(nblk), dim3(256), 0, g->stream, view(g), make_ghost(g, planes, ghost_lower, ghost_upper), mat, g->cand,
                        g->uf_on ? g->uf : nullptr, g->uf_list, g->uf_counts, segcap);
@@ -2118,14 +2130,15 @@ int cg_strip_sweep(cg_grid* g, int mat, int planes, const void* ghost_lower, con
         // the pieces of the material are joined once (and the ones that touch a seed hung under the mark); each call
         // then hangs what touches a marked node of the ghost rows under the mark too and marks every node whose root
         // the mark is: two launches the first time, one or two afterwards
+        const dim3 ufgrid(g->uf_nblk);                     // (the grid of the launch that made the lists)
         if (!g->uf_joined) {
-            hipLaunchKernelGGL(k_strip_union, grid, blk, 0, g->stream, view(g), mat, g->uf_list, g->uf_counts, g->uf_segcap, g->uf);
+            hipLaunchKernelGGL(k_strip_union, ufgrid, blk, 0, g->stream, view(g), mat, g->uf_list, g->uf_counts, g->uf_segcap, g->uf, 0);
             g->uf_joined = true;
         }
         if (gh.lo_len || gh.up_len)
             hipLaunchKernelGGL(k_strip_ghost, dim3((2 * (unsigned)g->ny + 255) / 256), blk, 0, g->stream, view(g), gh, mat, g->cand, g->uf);
         HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
-        hipLaunchKernelGGL(k_strip_spread, grid, blk, 0, g->stream, view(g), mat, g->cand, g->uf_list, g->uf_counts, g->uf_segcap, g->uf, g->d_flags);
+        hipLaunchKernelGGL(k_strip_spread, ufgrid, blk, 0, g->stream, view(g), mat, g->cand, g->uf_list, g->uf_counts, g->uf_segcap, g->uf, g->d_flags, (int*)nullptr);
         HIPCHK(g, hipGetLastError());
         int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
         if (changed) *changed = fl[0] ? 1 : 0;
@@ -2154,7 +2167,7 @@ int cg_strip_finish(cg_grid* g) {
     if (g->split) return fail(g, CG_ERR_STATE, "cg_strip_finish without cg_strip_seed");
     ProfScope ps(g, CG_K_OTHER);
     HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
-    hipLaunchKernelGGL(k_strip_compact, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_flags);
+    hipLaunchKernelGGL(k_strip_compact, dim3(blocks_for(g->N)), dim3(256), 0, g->stream, view(g), g->d_flags, (const uint8_t*)nullptr);
     HIPCHK(g, hipGetLastError());
     int fl[4]; int rc = read_flags(g, fl); if (rc) return rc;
     g->has_gaps = fl[2] != 0;
@@ -2210,6 +2223,41 @@ int cg_identify_cavity(cg_grid* g) {
     unsigned qtop = 0;
     int rc = refresh_len_bound(g, &qtop); if (rc) return rc;
     const unsigned hmax_q = qtop > 0 ? qtop : (unsigned)js_round(1.0 / g->zscale) & 0xffffu;        // maxHeight() is 1 for a flat-zero grid (cg2:103)
+    // The pass without the cavity layer that the reference lays on every column and strips again (k_cavity_scan): when
+    // that layer could not make the visible Lmax grow, the flood has its forest, and no column tops out at height 0.
+    static const bool no_scan = getenv("CG_CAVITY_FILL") != nullptr;
+    if (!no_scan && qtop > 0 && g->len_bound + 1 <= g->lmax_vis && g->N < ((size_t)1 << 32) && (g->N & 3) == 0) {
+        g->pend.active = false;
+        rc = ensure_whole(g); if (rc) return rc;
+        rc = strip_prepare(g, 4); if (rc) return rc;           // (k_cavity_scan: four columns per thread)
+        if (g->uf_on) {
+            const unsigned nblk = g->uf_nblk;
+            int fl[4];
+            {
+                ProfScope ps(g, CG_K_OTHER);
+                HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+                hipLaunchKernelGGL(k_cavity_scan, dim3(nblk), dim3(256), 0, g->stream, view(g), hmax_q, g->cand, g->uf, g->uf_list, g->uf_counts, g->uf_segcap, g->d_flags);
+                HIPCHK(g, hipGetLastError());
+            }
+            rc = read_flags(g, fl); if (rc) return rc;
+            if (!fl[0]) {
+                ProfScope ps(g, CG_K_OTHER);
+                const dim3 grid(nblk), blk(256);
+                HIPCHK(g, hipMemsetAsync(g->d_flags, 0, 4 * sizeof(int), g->stream));
+                hipLaunchKernelGGL(k_strip_union, grid, blk, 0, g->stream, view(g), CG_MAT_CAVITY, g->uf_list, g->uf_counts, g->uf_segcap, g->uf, 1);
+                // (flags: [0] a node was marked by the spread, [3] a cavity layer stays unmarked, [1] / [2] the compaction's)
+                hipLaunchKernelGGL(k_strip_spread, grid, blk, 0, g->stream, view(g), CG_MAT_CAVITY, g->cand, g->uf_list, g->uf_counts, g->uf_segcap, g->uf, g->d_flags, g->d_flags + 3);
+                hipLaunchKernelGGL(k_strip_compact, dim3(blocks_for(g->N / 4)), blk, 0, g->stream, view(g), g->d_flags, (const uint8_t*)g->cand);
+                HIPCHK(g, hipGetLastError());
+                rc = read_flags(g, fl); if (rc) return rc;
+                g->has_gaps = fl[2] != 0;
+                g->has_cavity = fl[1] != 0 || fl[3] != 0;
+                return CG_OK;
+            }
+            // (a column whose top lies at height 0: the gaps are cavity layers by now and the exposed ones carry their marks,
+            // which is what the passes below make of them too)
+        }
+    }
     rc = cg_cavity_fill(g, hmax_q); if (rc) return rc;
     return cg_strip_connected(g, CG_MAT_CAVITY);                                    // cg2:79
 }

@@ -220,6 +220,45 @@ def test_random_flow_vs_oracle(nx, ny, seed, stats):
     g.close()
 
 
+@pytest.mark.parametrize("zero_tops", [False, True])
+def test_cavity_pass_next_to_empty_columns_and_columns_at_height_zero(zero_tops):
+    """identify_cavity (cg2:9-83) on a grid with empty columns (a gap next to one is exposed, cg1:897) and, in the second
+    case, with columns whose only layer ends at height 0: the cavity layer the reference lays on such a column rests on the
+    floor and is NOT exposed (cg1:886), so it stays unless the flood reaches it -- the engine's pass that leaves those
+    layers out steps aside for the literal one there.  Both against the oracle, arrays and all."""
+    fem = _engine()
+    rng = _lcg(91)
+    nx, ny = 96, 128
+    g = fem.ColumnGrid(2 * nx, 2 * ny, 2, 2)
+    o = OracleGrid(2 * nx, 2 * ny, 2, 2)
+    masks = []
+    for _ in range(3):
+        red = fem.reduce_mask(_random_mask_data(rng, 2 * max(nx, ny), 6))
+        masks.append((g.mask_from_shapes(red), o.mask_raster(red)))
+    def both(fn, mi, *a):
+        if fn in ("strip_connected", "identify_cavity"):
+            getattr(g, fn)(*a); getattr(o, fn)(*a)
+        else:
+            gm, om = (None, None) if mi is None else masks[mi]
+            getattr(g, fn)(gm, *a); getattr(o, fn)(om, *a)
+        assert g.checksum() == o.checksum(), f"{fn} {mi} {a}"
+        assert g.maxHeight() == o.max_height() and g.Lmax == o.Lmax, f"{fn} {mi} {a}"
+    if zero_tops:
+        both("deposit_general", 0, 3, 0.04, 0)             # rounds to a layer from 0 to 0 where mask 0 is open
+    for mat, t in ((4, 10), (5, 6), (6, 8)):
+        both("deposit_general", 1, mat, t, 0)
+    both("etch_general", 2, 255, 30, 0)                    # open the stacks of mask 1 where mask 2 is open too
+    both("strip_connected", None, 5)                       # the exposed pieces of material 5 go: gaps under material 6
+    both("identify_cavity", None)
+    both("deposit_general", 1, 7, 4, 1.0)                  # a lateral deposit runs the pass again
+    both("strip_connected", None, 4)
+    both("identify_cavity", None)
+    both("etch_general", 1, 255, 5, 1.0)
+    both("identify_cavity", None)
+    _assert_same(g, o.arrays(), "final")
+    g.close()
+
+
 @pytest.mark.parametrize("nx,ny,seed", [(160, 224, 11), (301, 128, 12), (100, 90, 13)])
 def test_random_flow_with_strip_cmp_cavity_vs_oracle(nx, ny, seed):
     """Flows that create buried gaps and enclosed cavities: strip_connected, identify_cavity (through
