@@ -255,6 +255,15 @@ def test_cavity_pass_next_to_empty_columns_and_columns_at_height_zero(zero_tops)
     both("identify_cavity", None)
     both("etch_general", 1, 255, 5, 1.0)
     both("identify_cavity", None)
+    # material 2 laid down as a film (vertical and conformal): its layers are nodes of the pass like any cavity layer --
+    # the ones on the highest columns are exposed, the others are reached through the air above lower neighbours
+    both("deposit_general", 0, 2, 3, 0)
+    both("identify_cavity", None)
+    both("deposit_general", 2, 2, 5, 1.0)
+    both("deposit_general", None, 8, 2, 0)
+    both("identify_cavity", None)
+    both("etch_general", 2, 8, 3, 0)
+    both("identify_cavity", None)
     _assert_same(g, o.arrays(), "final")
     g.close()
 
